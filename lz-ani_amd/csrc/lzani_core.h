@@ -1,0 +1,462 @@
+// lzani_core.h -- the pair-path algorithm of the MI355X engine, as wave-structured code.
+//
+// What it replaces: CParser::{prepare_data, parse, calc_stats}
+// (/root/reference/src/parser.cpp:37-50, 482-716, 734-783) for one directed genome pair.
+//
+// Formulation (not a translation of the reference's loop):
+//   * texts are 2-bit packed (32 symbols per u64) with a separate N bitmask (64 per u64);
+//     a query is a *prefix view* of its own reference text (R = fwd | N^2mrd | RC | N^mrd,
+//     Q = fwd | N^mrd), so one device copy per genome serves both roles;
+//   * the greedy scan advances in ROUNDS of up to 64 query positions: every lane evaluates
+//     one position speculatively (anchor lookup; for the <= mqd+1 "tracking" steps also the
+//     close-seed search and the probabilistic arbitration) and the first lane that hits
+//     (ballot + ctz) is exactly the step the sequential scan would take, because between
+//     two hits the state evolves affinely (hard part 1);
+//   * no factor list: the calc_stats fold is applied on the fly from mismatch bitmasks
+//     (ballot + popcount + clz), with O(1) state per pair;
+//   * approximate extension consumes 64 symbols per step from a sliding 128-bit mismatch
+//     window instead of a circular flag buffer.
+//
+// The file is shared by the HIP kernels (wave = 64 lanes, lzani_kernels.hip) and by the
+// host-side lane-emulating model used only by the tests (tests/model/): the state machine
+// is templated on a `Wave` policy that supplies the cross-lane primitives.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LZ_HD __host__ __device__ __forceinline__
+#else
+#define LZ_HD inline
+#endif
+
+namespace lzani {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+struct Params {           // the eight ints CParser reads (params.h:34-48)
+    int mal, msl, mrd, mqd, reg, aw, am, ar;
+};
+
+struct TextView {         // one packed text: `len` symbols are addressable
+    const u64* t2;        // 2 bits per symbol, symbol j at bits 2*(j&31) of word j>>5
+    const u64* nm;        // 1 bit per symbol, 1 = N / padding
+    int len;
+};
+
+struct IndexView {        // anchor index of one reference (all mal-mers of R)
+    const u32* dirz;      // dirz[b] .. dirz[b+1] = entry range of bucket b
+    const u32* ent;       // (tag << posbits) | pos, ascending inside a bucket
+    int kb;               // 2*mal key bits
+    int dirbits;          // bucket = top dirbits of mix(key)
+    int posbits;          // low bits of an entry hold the position
+    u32 tagmask;          // stored tag bits
+};
+
+// ---- bit helpers --------------------------------------------------------------------
+LZ_HD u64 lowmask(int n) { return n >= 64 ? ~0ULL : (n <= 0 ? 0ULL : ((1ULL << n) - 1ULL)); }
+
+LZ_HD int popc64(u64 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+LZ_HD int ctz64(u64 x)      // x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((unsigned long long)x) - 1;
+#else
+    return __builtin_ctzll(x);
+#endif
+}
+LZ_HD int clz64(u64 x)      // x != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+LZ_HD int imin(int a, int b) { return a < b ? a : b; }
+LZ_HD int imax(int a, int b) { return a > b ? a : b; }
+LZ_HD int iabs(int a) { return a < 0 ? -a : a; }
+
+// 32 symbols (64 bits) starting at symbol p >= 0
+LZ_HD u64 win2(const u64* t2, int p)
+{
+    int w = p >> 5, s = (p & 31) * 2;
+    u64 lo = t2[w];
+    if (s == 0) return lo;
+    return (lo >> s) | (t2[w + 1] << (64 - s));
+}
+// 64 N flags starting at symbol p >= 0
+LZ_HD u64 winN(const u64* nm, int p)
+{
+    int w = p >> 6, s = p & 63;
+    u64 lo = nm[w];
+    if (s == 0) return lo;
+    return (lo >> s) | (nm[w + 1] << (64 - s));
+}
+LZ_HD int sym_at(const TextView& t, int p) { return (int)((t.t2[p >> 5] >> ((p & 31) * 2)) & 3ULL); }
+LZ_HD int isN_at(const TextView& t, int p) { return (int)((t.nm[p >> 6] >> (p & 63)) & 1ULL); }
+
+// 1 iff both positions exist, neither is N, and the symbols are equal.  N never matches
+// anything (reference: code_N_ref = 4 vs code_N_seq = 5, defs.h:28-30).
+LZ_HD int sym_match(const TextView& R, int rp, const TextView& Q, int qp)
+{
+    if (rp < 0 || rp >= R.len || qp < 0 || qp >= Q.len) return 0;
+    if (isN_at(R, rp) | isN_at(Q, qp)) return 0;
+    return sym_at(R, rp) == sym_at(Q, qp);
+}
+
+// equal_len (parser.cpp:192-207): common prefix of R[rp+start..] and Q[qp+start..], bounded by
+// both ends; returns `start` even if the bound is smaller (quirk Q11).
+LZ_HD int equal_len(const TextView& R, int rp, const TextView& Q, int qp, int start)
+{
+    int bound = imin(R.len - rp, Q.len - qp);
+    int n = start;
+    while (n < bound) {
+        u64 x = win2(R.t2, rp + n) ^ win2(Q.t2, qp + n);
+        u64 d = (x | (x >> 1)) & 0x5555555555555555ULL;
+        u32 nn = (u32)(winN(R.nm, rp + n) | winN(Q.nm, qp + n));
+        int fd = d ? (ctz64(d) >> 1) : 32;
+        int fn = nn ? ctz64((u64)nn) : 32;
+        int f = imin(fd, fn);
+        if (f < 32) { n += f; return n < bound ? n : (bound > start ? bound : start); }
+        n += 32;
+    }
+    return n < bound ? n : (bound > start ? bound : start);
+}
+
+// k-mer (k <= 32) starting at p; returns false if it overlaps an N or the end of the text
+LZ_HD bool kmer_at(const TextView& t, int p, int k, u64& key)
+{
+    if (p < 0 || p + k > t.len) return false;
+    if (winN(t.nm, p) & lowmask(k)) return false;
+    key = win2(t.t2, p) & lowmask(2 * k);
+    return true;
+}
+
+// Bijective mixer on kb bits: (bucket, tag) = (top dirbits, remaining low bits) identify the key.
+LZ_HD u64 mix_key(u64 key, int kb)
+{
+    if (kb <= 32) {
+        u32 m = kb >= 32 ? 0xFFFFFFFFu : ((1u << kb) - 1u);
+        u32 x = (u32)key;
+        x = (x * 0x9E3779B1u) & m;
+        x ^= x >> ((kb + 1) >> 1);
+        x = (x * 0x85EBCA6Bu) & m;
+        x ^= x >> ((kb + 1) >> 1);
+        x = (x * 0xC2B2AE35u) & m;
+        return x;
+    }
+    u64 m = lowmask(kb);
+    u64 x = key;
+    x = (x * 0x9E3779B97F4A7C15ULL) & m;
+    x ^= x >> ((kb + 1) >> 1);
+    x = (x * 0xD6E8FEB86659FD93ULL) & m;
+    x ^= x >> ((kb + 1) >> 1);
+    x = (x * 0xC2B2AE3D27D4EB4FULL) & m;
+    return x;
+}
+LZ_HD void key_slot(const IndexView& I, u64 key, u32& bucket, u32& tag)
+{
+    u64 h = mix_key(key, I.kb);
+    int tb = I.kb - I.dirbits;
+    bucket = (u32)(h >> tb);
+    tag = (u32)(h & lowmask(tb)) & I.tagmask;
+}
+
+// best_anchor (parser.cpp:514-531 == 585-602): over the reference positions holding the same
+// mal-mer, ascending, the longest common prefix >= mal; first (smallest position) wins ties.
+LZ_HD void best_anchor(const Params& P, const TextView& R, const TextView& Q, const IndexView& I,
+                       int qp, int& ap, int& al)
+{
+    ap = 0; al = 0;
+    u64 key;
+    if (!kmer_at(Q, qp, P.mal, key)) return;
+    u32 b, tag;
+    key_slot(I, key, b, tag);
+    u32 s = I.dirz[b], e = I.dirz[b + 1];
+    u32 pm = (u32)lowmask(I.posbits);
+    for (u32 j = s; j < e; ++j) {
+        u32 en = I.ent[j];
+        if ((en >> I.posbits) != tag) continue;
+        int p = (int)(en & pm);
+        int m = equal_len(R, p, Q, qp, 0);
+        if (m >= P.mal && m > al) { al = m; ap = p; }
+    }
+}
+
+// Seed selection rule (parser.cpp:566-578): longer wins; on a tie the one strictly nearer to
+// ref_pred; candidates must be offered in ascending position.
+LZ_HD void seed_consider(int p, int m, int ref_pred, int& sp, int& sl)
+{
+    if (m >= sl) {
+        if (m == sl) { if (iabs(p - ref_pred) < iabs(sp - ref_pred)) sp = p; }
+        else { sl = m; sp = p; }
+    }
+}
+
+// ipow<double>(1 - 4^-len, e) (parser.h:134-188): square and multiply, IEEE doubles, the same
+// multiplication order as the reference so the comparison in `arbitrate` is bit-exact.
+LZ_HD double pow_not_chance(int len, u32 e)
+{
+    double base = 1.0;
+    if (len < 27) {                      // 1 - 4^-len is exactly 1.0 from len = 27 on (quirk Q5)
+        double p = 1.0;
+        for (int j = 0; j < len; ++j) p *= 0.25;
+        base = 1.0 - p;
+    }
+    double r = 1.0;
+    while (e) {
+        if (e & 1u) r *= base;
+        base *= base;
+        e >>= 1;
+    }
+    return r;
+}
+
+// Arbitration between the close seed (sp,sl) and the anchor (ap,al) in tracking mode
+// (parser.cpp:604-623), with the 0-position sentinels of quirk Q1 kept.
+LZ_HD void arbitrate(const Params& P, int T, int lit, int ap, int al, int& sp, int& sl)
+{
+    if (!ap) return;
+    if (!sp) { sp = ap; sl = al; return; }
+    u32 ea = (u32)(int)(2 * ((u64)T + 1 - (u64)(int64_t)al));     // (int) cast, then uint32_t parameter (Q4)
+    u32 ec = (u32)(lit + P.mrd + 1 - sl);
+    double anchor_prob = pow_not_chance(al, ea);
+    double close_prob = pow_not_chance(sl, ec);
+    if (anchor_prob > close_prob) { sp = ap; sl = al; }
+}
+
+// One scan step evaluated in isolation (what one lane does in a round).
+//   trk   : the step starts in tracking mode (ref_pred >= 0)
+//   r_end : reference end of the last match (= ref_pred - lit)
+//   lit   : literal run length at the start of this step
+// Portable version of the close-seed search (window scan); the HIP wave uses a shared-window
+// variant with the same candidate order (lzani_kernels.hip).
+LZ_HD void eval_step(const Params& P, const TextView& R, const TextView& Q, const IndexView& I,
+                     int qp, bool trk, int r_end, int lit, int& bp, int& bl)
+{
+    int ap, al;
+    best_anchor(P, R, Q, I, qp, ap, al);
+    if (!trk) { bp = ap; bl = al; return; }
+    int sp = 0, sl = 0;
+    u64 qk;
+    if (kmer_at(Q, qp, P.msl, qk)) {
+        int ref_pred = r_end + lit;
+        int hi = imin(ref_pred + P.mrd, R.len - P.msl + 1);
+        for (int p = r_end; p < hi; ++p) {
+            u64 rk;
+            if (!kmer_at(R, p, P.msl, rk) || rk != qk) continue;
+            seed_consider(p, equal_len(R, p, Q, qp, P.msl), ref_pred, sp, sl);
+        }
+    }
+    arbitrate(P, R.len, lit, ap, al, sp, sl);
+    bp = sp; bl = sl;
+}
+
+// ---- streaming calc_stats state --------------------------------------------------------
+struct Regions {
+    int cl, clit, nl;      // open region: matches, literals between matches, pending literals
+    int tm, tl, tc;        // totals over finalised regions with cl + clit >= reg
+    int reg;
+    LZ_HD void init(int r) { cl = clit = nl = tm = tl = tc = 0; reg = r; }
+    // calc_stats at a match_distant factor (parser.cpp:743-751): close the open region
+    LZ_HD void finalize()
+    {
+        if (cl && cl + clit >= reg) { tm += cl; tl += clit; ++tc; }
+        cl = clit = nl = 0;
+    }
+    LZ_HD void discard() { cl = clit = nl = 0; }
+    // fold of `n` symbols whose match flags are the low n bits of M (bit j = symbol j)
+    LZ_HD void seg(u64 M, int n)
+    {
+        if (M) {
+            int hi = 63 - clz64(M);
+            int c = popc64(M);
+            cl += c;
+            clit += nl + (hi + 1 - c);
+            nl = n - 1 - hi;
+        } else nl += n;
+    }
+    LZ_HD void seg_match_run(int n) { if (n > 0) { cl += n; clit += nl; nl = 0; } }
+};
+
+// Result of scanning one 64-symbol chunk of an approximate extension (try_extend_*,
+// parser.cpp:377-441).  prevB/B are mismatch masks of the previous/current chunk (bit j =
+// symbol j of the chunk; symbols before the start of the extension count as matches).
+//   brk  : bit j set iff the sliding window ending at j holds more than am mismatches
+//   qual : bit j set iff j is a match and the ar-1 symbols before it are matches too
+struct ExtMasks { u64 brk, qual; };
+
+LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool& brk, bool& qual)
+{
+    // 128-bit stream: prevB is symbols -64..-1, B is symbols 0..63; window (j-aw, j]
+    brk = false; qual = false;
+    if (j >= n) return;
+    int lo = j - aw + 1;                       // may be negative (reaches into prevB)
+    int cnt;
+    if (lo >= 0) cnt = popc64((B >> lo) & lowmask(aw));
+    else cnt = popc64(B & lowmask(j + 1)) + popc64(prevB >> (64 + lo));
+    brk = cnt > am;
+    int a = ar < 1 ? 1 : ar;
+    int lo2 = j - a + 1;
+    u64 bad;
+    if (lo2 >= 0) bad = (B >> lo2) & lowmask(a);
+    else bad = (B & lowmask(j + 1)) | (prevB >> (64 + lo2));
+    qual = bad == 0;
+}
+
+// ---- the pair state machine ------------------------------------------------------------
+// Wave policy W must provide (all results wave-uniform):
+//   u64  mism_fwd(q0, r0, n)       bit j (j<n) = 1 iff Q[q0+j] does not match R[r0+j]
+//   u64  mism_bwd(q0, r0, n)       bit j (j<n) = 1 iff Q[q0-1-j] does not match R[r0-1-j]
+//   bool find_event(i, n, trk, r_end, lit, lane, bpos, blen)
+//                                   first step l in [0,n) whose evaluation gives len >= msl
+//   ExtMasks ext_scan(prevB, B, n)
+//   int  best_split(Lm, Rm, to_scan) argmax_s popc(Lm & low(s)) + popc(Rm >> s), last max wins
+template <class W>
+struct PairMachine {
+    W& w;
+    const Params& P;
+    const int T, D;
+    Regions g;
+
+    LZ_HD PairMachine(W& w_, const Params& P_, int T_, int D_) : w(w_), P(P_), T(T_), D(D_) { g.init(P_.reg); }
+
+    // compare_ranges folded (parser.cpp:210-248): any length, forward order
+    LZ_HD void seg_range(int q0, int r0, int len)
+    {
+        for (int base = 0; base < len; base += 64) {
+            int n = imin(64, len - base);
+            u64 B = w.mism_fwd(q0 + base, r0 + base, n);
+            g.seg(~B & lowmask(n), n);
+        }
+    }
+
+    // try_extend_forward (parser.cpp:377-409) fused with the fold of compare_ranges(i, ref_pred, e)
+    LZ_HD int extend_forward(int q0, int r0)
+    {
+        int maxlen = imin(D - q0, T - r0);
+        int last = 0, last_mm = 0, mm_cum = 0;
+        u64 prevB = 0;
+        for (int base = 0; base < maxlen; base += 64) {
+            int n = imin(64, maxlen - base);
+            u64 B = w.mism_fwd(q0 + base, r0 + base, n);
+            ExtMasks m = w.ext_scan(prevB, B, n);
+            u64 qm = m.qual;
+            if (m.brk) qm &= lowmask(ctz64(m.brk) + 1);
+            if (qm) {
+                int jq = 63 - clz64(qm);
+                last = base + jq + 1;
+                last_mm = mm_cum + popc64(B & lowmask(jq + 1));
+            }
+            if (m.brk) break;
+            mm_cum += popc64(B);
+            prevB = B;
+        }
+        if (last > 0) {            // position last-1 is a match, so every mismatch precedes a match
+            g.cl += last - last_mm;
+            g.clit += g.nl + last_mm;
+            g.nl = 0;
+        }
+        return last;
+    }
+
+    // try_extend_backward (parser.cpp:412-441)
+    LZ_HD int extend_backward(int q0, int r0, int max_len)
+    {
+        int maxlen = imin(max_len, imin(q0, r0));
+        int last = 0;
+        u64 prevB = 0;
+        for (int base = 0; base < maxlen; base += 64) {
+            int n = imin(64, maxlen - base);
+            u64 B = w.mism_bwd(q0 - base, r0 - base, n);
+            ExtMasks m = w.ext_scan(prevB, B, n);
+            u64 qm = m.qual;
+            if (m.brk) qm &= lowmask(ctz64(m.brk) + 1);
+            if (qm) last = base + (63 - clz64(qm)) + 1;
+            if (m.brk) break;
+            prevB = B;
+        }
+        return last;
+    }
+
+    // compare_ranges_both_ways folded (parser.cpp:251-374); len = literal run <= 64
+    LZ_HD void gap_fill(int ds, int r_left, int r_right_end, int len)
+    {
+        if (len <= 0) return;
+        int to_scan = (r_right_end < r_left) ? len : imin(r_right_end - r_left, len);
+        int shift = len - to_scan;
+        u64 F = 0;
+        if (to_scan > 0) {
+            u64 Lm = ~w.mism_fwd(ds, r_left, to_scan) & lowmask(to_scan);
+            u64 Rm = ~w.mism_fwd(ds + shift, r_right_end - to_scan, to_scan) & lowmask(to_scan);
+            int s = w.best_split(Lm, Rm, to_scan);
+            u64 right = (s >= 64) ? 0ULL : ((Rm >> s) << s);
+            F = (Lm & lowmask(s)) | (right << shift);
+        }
+        g.seg(F, len);
+    }
+
+    LZ_HD void run(int out[3])
+    {
+        int i = 0, lit = 0, r_end = 0;
+        bool trk = false;
+        int prev_rs = -1, prev_re = 0, pre_lit = 0;
+        const int iend = D - P.msl;              // loop condition i + msl < |Q| (quirk Q10)
+
+        while (i < iend) {
+            int n = imin(64, iend - i);
+            int lane = 0, bpos = 0, blen = 0;
+            if (!w.find_event(i, n, trk, r_end, lit, lane, bpos, blen)) {
+                i += n; lit += n;
+                if (lit > P.mqd) trk = false;
+                continue;
+            }
+            i += lane; lit += lane;
+            bool strk = trk && lit <= P.mqd;
+            int ref_pred = r_end + lit;
+            if (strk && iabs(bpos - ref_pred) <= P.mrd) {
+                // close match: fill the gap, then the match itself (parser.cpp:630-635; quirk Q2)
+                gap_fill(i - lit, r_end, bpos + blen, lit);
+                g.seg_match_run(blen);
+            } else {
+                // distant match (parser.cpp:636-685)
+                int avail;
+                if (prev_rs >= 0 && prev_re - prev_rs < P.reg) {       // drop the short region
+                    avail = pre_lit + (i - prev_rs);
+                    g.discard();
+                    prev_rs = -1;
+                } else avail = lit;
+                int b = avail > 0 ? extend_backward(i, bpos, avail) : 0;
+                g.finalize();                                           // a match_distant factor follows
+                if (b > 0) {
+                    pre_lit = avail - b;
+                    seg_range(i - b, bpos - b, b);
+                    prev_rs = i - b;
+                } else { pre_lit = avail; prev_rs = i; }
+                g.seg_match_run(blen);
+            }
+            i += blen;
+            r_end = bpos + blen;
+            lit = 0;
+            trk = true;
+            int e = extend_forward(i, r_end);
+            i += e; r_end += e;
+            prev_re = i;
+        }
+        if (trk)   // tail compare against r_end - msl (parser.cpp:713, quirk Q3)
+            seg_range(i - lit, r_end - P.msl, lit + (D - i));
+        g.finalize();
+        out[0] = g.tm; out[1] = g.tl; out[2] = g.tc;
+    }
+};
+
+}  // namespace lzani

@@ -1,0 +1,160 @@
+// lzani_model.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Host build of the product's pair state machine (lz-ani_amd/csrc/lzani_core.h) with a
+// lane-emulating Wave policy: each cross-lane primitive is a plain loop over 64 lanes.  It lets
+// the CPU test suite (-m "not gpu") check the exact kernel formulation -- rounds, mismatch-mask
+// folds, chunked extensions, gap-fill split -- against the oracle without a GPU.  It is not a
+// fallback: nothing in lz-ani_amd/ links or loads it.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../lz-ani_amd/csrc/lzani_core.h"
+#include "../../lz-ani_amd/csrc/lzani_layout.h"
+
+using namespace lzani;
+
+namespace {
+
+struct Genome {
+    int L, T, D;
+    std::vector<u64> t2, nm;
+    std::vector<u32> dirz, ent;
+    IndexView iv;
+    TextView rview() const { return TextView{t2.data(), nm.data(), T}; }
+    TextView qview() const { return TextView{t2.data(), nm.data(), D}; }
+};
+
+void pack_genome(Genome& g, const uint8_t* codes, int L, const Params& P)
+{
+    g.L = L; g.T = ref_text_len(L, P.mrd); g.D = L + P.mrd;
+    size_t w2 = text_words2(g.T), wn = text_wordsN(g.T);
+    g.t2.assign(w2, 0);
+    g.nm.assign(wn, ~0ULL);
+    auto put = [&](int p, int c) {
+        if (c < 4) {
+            g.t2[p >> 5] |= (u64)c << ((p & 31) * 2);
+            g.nm[p >> 6] &= ~(1ULL << (p & 63));
+        }
+    };
+    for (int j = 0; j < L; ++j) put(j, codes[j] < 4 ? codes[j] : 4);
+    int rc0 = L + 2 * P.mrd;
+    for (int j = 0; j < L; ++j) { int c = codes[L - 1 - j]; put(rc0 + j, c < 4 ? 3 - c : 4); }
+}
+
+void build_index(Genome& g, const Params& P, const IndexGeom& geo)
+{
+    g.iv.kb = geo.kb; g.iv.dirbits = geo.dirbits; g.iv.posbits = geo.posbits; g.iv.tagmask = geo.tagmask;
+    size_t nb = (size_t)1 << geo.dirbits;
+    g.dirz.assign(nb + 1, 0);
+    TextView R = g.rview();
+    std::vector<std::pair<u32, u32>> items;   // (bucket, entry)
+    for (int p = 0; p + P.mal <= g.T; ++p) {
+        u64 key;
+        if (!kmer_at(R, p, P.mal, key)) continue;
+        u32 b, tag;
+        key_slot(g.iv, key, b, tag);
+        items.emplace_back(b, (tag << geo.posbits) | (u32)p);
+    }
+    std::sort(items.begin(), items.end());
+    g.ent.resize(items.size() + 1);
+    for (size_t k = 0; k < items.size(); ++k) { g.ent[k] = items[k].second; g.dirz[items[k].first + 1]++; }
+    for (size_t b = 0; b < nb; ++b) g.dirz[b + 1] += g.dirz[b];
+    g.iv.dirz = g.dirz.data(); g.iv.ent = g.ent.data();
+}
+
+struct HostWave {
+    const Params& P;
+    TextView R, Q;
+    IndexView I;
+
+    u64 mism_fwd(int q0, int r0, int n) const
+    {
+        u64 m = 0;
+        for (int j = 0; j < n; ++j) if (!sym_match(R, r0 + j, Q, q0 + j)) m |= 1ULL << j;
+        return m;
+    }
+    u64 mism_bwd(int q0, int r0, int n) const
+    {
+        u64 m = 0;
+        for (int j = 0; j < n; ++j) if (!sym_match(R, r0 - 1 - j, Q, q0 - 1 - j)) m |= 1ULL << j;
+        return m;
+    }
+    bool find_event(int i, int n, bool trk, int r_end, int lit, int& lane, int& bpos, int& blen) const
+    {
+        for (int l = 0; l < n; ++l) {
+            int bp, bl;
+            eval_step(P, R, Q, I, i + l, trk && (lit + l <= P.mqd), r_end, lit + l, bp, bl);
+            if (bl >= P.msl) { lane = l; bpos = bp; blen = bl; return true; }
+        }
+        return false;
+    }
+    ExtMasks ext_scan(u64 prevB, u64 B, int n) const
+    {
+        ExtMasks m{0, 0};
+        for (int j = 0; j < 64; ++j) {
+            bool b, q;
+            ext_lane(prevB, B, j, n, P.aw, P.am, P.ar, b, q);
+            if (b) m.brk |= 1ULL << j;
+            if (q) m.qual |= 1ULL << j;
+        }
+        return m;
+    }
+    int best_split(u64 Lm, u64 Rm, int to_scan) const
+    {
+        int best = -1, bs = 0;
+        for (int s = 0; s <= to_scan; ++s) {
+            int v = popc64(Lm & lowmask(s)) + (s >= 64 ? 0 : popc64(Rm >> s));
+            if (v >= best) { best = v; bs = s; }
+        }
+        return bs;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// out[(r*n + q)*3 ..] = parse(query=q, ref=r); diagonal zero.  Returns 0, or -1 on unsupported params.
+int model_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t* len, const int32_t* p8, int32_t* out)
+{
+    Params P{p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]};
+    if (!params_supported(P)) return -1;
+    uint32_t maxL = 0;
+    for (uint32_t i = 0; i < n; ++i) maxL = std::max(maxL, len[i]);
+    IndexGeom geo = index_geometry(ref_text_len((int)maxL, P.mrd), P.mal);
+    std::vector<Genome> G(n);
+    for (uint32_t i = 0; i < n; ++i) { pack_genome(G[i], codes[i], (int)len[i], P); build_index(G[i], P, geo); }
+    for (uint32_t r = 0; r < n; ++r)
+        for (uint32_t q = 0; q < n; ++q) {
+            int32_t* o = out + ((size_t)r * n + q) * 3;
+            if (r == q) { o[0] = o[1] = o[2] = 0; continue; }
+            HostWave w{P, G[r].rview(), G[q].qview(), G[r].iv};
+            PairMachine<HostWave> m(w, P, G[r].T, G[q].D);
+            int res[3];
+            m.run(res);
+            o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+        }
+    return 0;
+}
+
+// Packed text + index of one genome exactly as the device builds them (for the GPU index test).
+int model_index(const uint8_t* codes, uint32_t len, uint32_t max_len, const int32_t* p8,
+                uint64_t* t2, uint64_t* nm, uint32_t* dirz, uint32_t* ent, uint32_t* n_ent)
+{
+    Params P{p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]};
+    if (!params_supported(P)) return -1;
+    IndexGeom geo = index_geometry(ref_text_len((int)max_len, P.mrd), P.mal);
+    Genome g;
+    pack_genome(g, codes, (int)len, P);
+    build_index(g, P, geo);
+    if (t2) memcpy(t2, g.t2.data(), g.t2.size() * 8);
+    if (nm) memcpy(nm, g.nm.data(), g.nm.size() * 8);
+    if (dirz) memcpy(dirz, g.dirz.data(), g.dirz.size() * 4);
+    if (ent) memcpy(ent, g.ent.data(), (g.ent.size() - 1) * 4);
+    if (n_ent) *n_ent = (uint32_t)(g.ent.size() - 1);
+    return 0;
+}
+
+}  // extern "C"
