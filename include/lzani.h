@@ -1,0 +1,105 @@
+/*
+ * lzani.h -- C ABI of the MI355X LZ-ANI pair engine (liblzani_hip.so).
+ *
+ * This is the drop-in boundary for LZ-ANI's one data-parallel hot path: the worker loop of
+ * CLZMatcher::do_matching (/root/reference/src/lz_matcher.cpp:172-277) and everything it calls
+ * in CParser (/root/reference/src/parser.h:237-253, parser.cpp:16-783).  A host that owns
+ * FASTA ingest, filtering and TSV output (the reference's CLZMatcher, or this repo's own
+ * `lz-ani` binary) hands over genomes as reservoir symbol codes and rows of directed pairs,
+ * and receives one results_t per pair.  Plain pointers and sizes only; no HIP, torch or C++
+ * types cross the boundary.  INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions: every function returns LZANI_OK (0) or a negative error code and never calls
+ * exit(); lzani_last_error() gives the message.  A context is bound to one GPU, is blocking
+ * and not re-entrant (the reference's per-thread CParser has the same property, parser.h:25-56).
+ * Outputs are written only on success.
+ */
+#ifndef LZANI_H
+#define LZANI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZANI_OK             0
+#define LZANI_ERR_ARG       -1   /* NULL / out-of-range argument                           */
+#define LZANI_ERR_PARAMS    -2   /* LZ parameters outside the supported envelope           */
+#define LZANI_ERR_DEVICE    -3   /* HIP runtime error (message in lzani_last_error)        */
+#define LZANI_ERR_STATE     -4   /* call order violated (e.g. run before set_genomes)      */
+#define LZANI_ERR_NOMEM     -5   /* host or device allocation failed                       */
+
+/* The eight integers CParser reads from CParams (/root/reference/src/params.h:34-48;
+ * CLI: -a/--mal -s/--msl -r/--mrd -q/--mqd -g/--reg --aw --am --ar, lz-ani.cpp:210-249). */
+typedef struct lzani_params {
+    int32_t min_anchor_len;     /* mal, default 11 */
+    int32_t min_seed_len;       /* msl, default 7  */
+    int32_t max_dist_in_ref;    /* mrd, default 40 */
+    int32_t max_dist_in_query;  /* mqd, default 40 */
+    int32_t min_region_len;     /* reg, default 35 */
+    int32_t approx_window;      /* aw,  default 15 */
+    int32_t approx_mismatches;  /* am,  default 7  */
+    int32_t approx_run_len;     /* ar,  default 3  */
+} lzani_params;
+
+/* results_t (/root/reference/src/defs.h:48-65): what CParser::calc_stats returns. */
+typedef struct lzani_result {
+    int32_t sym_in_matches;     /* TSV nt_match    */
+    int32_t sym_in_literals;    /* TSV nt_mismatch */
+    int32_t no_components;      /* TSV num_alns    */
+} lzani_result;
+
+/* Device-side timing of the last lzani_run_rows* call, measured with HIP events on the
+ * context's own stream (what bench.py reports as the roofline numerator/denominator). */
+typedef struct lzani_timing {
+    double   index_ms;          /* sum over batches: per-reference index build kernels      */
+    double   pairs_ms;          /* sum over batches: the pair kernel                        */
+    uint32_t pair_launches;     /* number of pair-kernel launches (= batches)               */
+    uint32_t index_launches;    /* number of index-build kernel launches                    */
+    uint64_t pairs;             /* directed pairs processed                                 */
+} lzani_timing;
+
+typedef struct lzani_ctx lzani_ctx;
+
+void lzani_default_params(lzani_params *p);
+
+/* Replaces CParser::CParser(const CParams&) (parser.h:237-241), once per GPU instead of once
+ * per thread.  device_id is the HIP device ordinal. */
+int lzani_create(const lzani_params *p, int device_id, lzani_ctx **out);
+void lzani_destroy(lzani_ctx *ctx);
+const char *lzani_last_error(const lzani_ctx *ctx);
+
+/* Replaces the seq_view hand-over of prepare_reference / prepare_data (parser.cpp:16-50;
+ * lz_matcher.cpp:207-221): all n genomes at once, one symbol per byte in the reservoir's
+ * codes (A0 C1 G2 T3, anything >= 4 is N; seq_reservoir.h:241-248).  The engine packs them to
+ * 2 bit + N mask on the device and keeps them resident; caller buffers may be freed on return.
+ * Ids used below are indices into this table (the reference's reordered sequence ids). */
+int lzani_set_genomes(lzani_ctx *ctx, uint32_t n, const uint8_t *const *codes, const uint32_t *len);
+
+/* Replaces the body of the do_matching worker (lz_matcher.cpp:196-255) for n_rows reference
+ * rows given in CSR form: row k has reference ref_ids[k] and queries
+ * query_ids[row_off[k] .. row_off[k+1]).  query_ids == NULL means the dense row "every id !=
+ * ref, ascending" (row_off[k+1]-row_off[k] must then be n-1), i.e. lz_matcher.cpp:214-233;
+ * a non-NULL list is the filtered case (234-250).  out is CSR-aligned (out[e] belongs to
+ * query_ids[e]) in host memory: out[e] = calc_stats() of parse(query = query_ids[e], ref = ref_ids[k]). */
+int lzani_run_rows(lzani_ctx *ctx, uint32_t n_rows, const uint32_t *ref_ids, const uint64_t *row_off,
+                   const uint32_t *query_ids, lzani_result *out);
+
+/* Same, but the results stay in device memory: d_out is a device pointer (this context's GPU)
+ * to row_off[n_rows] lzani_result records, e.g. the shard buffer handed to an RCCL gather. */
+int lzani_run_rows_device(lzani_ctx *ctx, uint32_t n_rows, const uint32_t *ref_ids, const uint64_t *row_off,
+                          const uint32_t *query_ids, void *d_out);
+
+int lzani_get_timing(const lzani_ctx *ctx, lzani_timing *t);
+
+/* Test hook: copies out the device-built packed reference text and anchor index of one genome
+ * (any pointer may be NULL).  Sizes: nm = ((T+63)/64+2) u64, t2 = twice that, with
+ * T = 2*len+3*mrd; dirz = 2^dirbits+1 u32; ent <= T u32.  geom = {kb, dirbits, posbits, tagmask}. */
+int lzani_debug_get_index(lzani_ctx *ctx, uint32_t id, uint64_t *t2, uint64_t *nm,
+                          uint32_t *dirz, uint32_t *ent, uint32_t *n_ent, uint32_t *geom);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

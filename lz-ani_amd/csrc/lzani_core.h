@@ -30,6 +30,16 @@
 #define LZ_HD inline
 #endif
 
+// Loop guard: every data-dependent loop has a bound that correct data can never reach; a trip is
+// recorded (device: in g_guard_trip, read back by the host) and the loop is left, so that every
+// wave of the persistent pair kernel reaches its exit whatever the data.
+#if defined(__HIP_DEVICE_COMPILE__)
+extern __device__ int g_guard_trip;
+#define LZ_GUARD_TRIP(code) (g_guard_trip = (code))
+#else
+#define LZ_GUARD_TRIP(code) ((void)(code))
+#endif
+
 namespace lzani {
 
 typedef uint64_t u64;
@@ -119,7 +129,9 @@ LZ_HD int equal_len(const TextView& R, int rp, const TextView& Q, int qp, int st
 {
     int bound = imin(R.len - rp, Q.len - qp);
     int n = start;
+    int guard = 0;
     while (n < bound) {
+        if (++guard > (1 << 26)) { LZ_GUARD_TRIP(1); break; }
         u64 x = win2(R.t2, rp + n) ^ win2(Q.t2, qp + n);
         u64 d = (x | (x >> 1)) & 0x5555555555555555ULL;
         u32 nn = (u32)(winN(R.nm, rp + n) | winN(Q.nm, qp + n));
@@ -183,6 +195,7 @@ LZ_HD void best_anchor(const Params& P, const TextView& R, const TextView& Q, co
     key_slot(I, key, b, tag);
     u32 s = I.dirz[b], e = I.dirz[b + 1];
     u32 pm = (u32)lowmask(I.posbits);
+    if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); return; }
     for (u32 j = s; j < e; ++j) {
         u32 en = I.ent[j];
         if ((en >> I.posbits) != tag) continue;
@@ -251,10 +264,15 @@ LZ_HD void eval_step(const Params& P, const TextView& R, const TextView& Q, cons
     if (kmer_at(Q, qp, P.msl, qk)) {
         int ref_pred = r_end + lit;
         int hi = imin(ref_pred + P.mrd, R.len - P.msl + 1);
-        for (int p = r_end; p < hi; ++p) {
-            u64 rk;
-            if (!kmer_at(R, p, P.msl, rk) || rk != qk) continue;
-            seed_consider(p, equal_len(R, p, Q, qp, P.msl), ref_pred, sp, sl);
+        const int step = 33 - P.msl;             // window positions served by one 32-symbol load
+        const u64 km = lowmask(2 * P.msl), nk = lowmask(P.msl);
+        for (int p0 = r_end; p0 < hi; p0 += step) {
+            u64 w2 = win2(R.t2, p0), wn = winN(R.nm, p0);
+            int cnt = imin(step, hi - p0);
+            for (int o = 0; o < cnt; ++o) {
+                if (((w2 >> (2 * o)) & km) != qk || ((wn >> o) & nk)) continue;
+                seed_consider(p0 + o, equal_len(R, p0 + o, Q, qp, P.msl), ref_pred, sp, sl);
+            }
         }
     }
     arbitrate(P, R.len, lit, ap, al, sp, sl);
@@ -411,8 +429,10 @@ struct PairMachine {
         bool trk = false;
         int prev_rs = -1, prev_re = 0, pre_lit = 0;
         const int iend = D - P.msl;              // loop condition i + msl < |Q| (quirk Q10)
+        int rounds = 0;                          // every round advances i by >= 1: hard exit bound
 
         while (i < iend) {
+            if (++rounds > D + 8) { LZ_GUARD_TRIP(3); out[0] = -1; out[1] = i; out[2] = lit; return; }
             int n = imin(64, iend - i);
             int lane = 0, bpos = 0, blen = 0;
             if (!w.find_event(i, n, trk, r_end, lit, lane, bpos, blen)) {

@@ -1,0 +1,651 @@
+// lzani_hip.hip -- HIP kernels for gfx950 (MI355X) and the C-ABI (include/lzani.h) above them.
+//
+// Kernels (all integer / bit work, HBM- and L2-bound; no MFMA by design):
+//   k_pack        reservoir codes -> packed reference text  fwd | N^2mrd | RC | N^mrd
+//                 (replaces seq_view::unpack + CParser::append/append_rc, parser.h:57-96)
+//   k_idx_count / k_idx_scan / k_idx_fill / k_idx_sort
+//                 per-reference anchor index of all mal-mers (replaces prepare_kmers +
+//                 prepare_ht_long, parser.cpp:53-103, 146-189): bucket directory + (tag|pos)
+//                 entries, ascending inside a bucket
+//   k_pairs       one wavefront per directed genome pair, persistent waves pulling pairs from
+//                 an atomic cursor in reference-major order (replaces prepare_data + parse +
+//                 calc_stats, parser.cpp:37-50, 482-716, 734-783, and the worker loop of
+//                 do_matching, lz_matcher.cpp:192-269)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lzani.h"
+
+__device__ int g_guard_trip = 0;   // see LZ_GUARD_TRIP in lzani_core.h
+
+#include "lzani_core.h"
+#include "lzani_layout.h"
+
+namespace lzani {
+
+struct GenomeTab {
+    const u64* t2;       // all packed texts, concatenated
+    const u64* nm;       // all N masks, concatenated
+    const u64* nmoff;    // per genome: word offset into nm (t2 offset is twice that)
+    const int* L;        // per genome: sequence length
+};
+
+// ------------------------------------------------------------------------------------------
+// k_pack: one thread per 64-symbol block of a reference text.
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack(const uint8_t* __restrict__ codes, const u64* __restrict__ codeoff,
+                       u64* __restrict__ t2, u64* __restrict__ nm, const u64* __restrict__ nmoff,
+                       const int* __restrict__ Ls, int mrd, u32 n)
+{
+    u32 g = blockIdx.y;
+    if (g >= n) return;
+    int L = Ls[g];
+    int T = ref_text_len(L, mrd);
+    size_t nblk = text_wordsN(T);
+    size_t blk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nblk) return;
+    const uint8_t* c = codes + codeoff[g];
+    u64 w0 = 0, w1 = 0, nw = 0;
+    int rc0 = L + 2 * mrd;
+    for (int j = 0; j < 64; ++j) {
+        long p = (long)blk * 64 + j;
+        int s = 4;
+        if (p < L) { int v = c[p]; s = v < 4 ? v : 4; }
+        else if (p >= rc0 && p < rc0 + L) { int v = c[L - 1 - (p - rc0)]; s = v < 4 ? 3 - v : 4; }
+        if (s < 4) {
+            if (j < 32) w0 |= (u64)s << (2 * j);
+            else w1 |= (u64)s << (2 * (j - 32));
+        } else nw |= 1ULL << j;
+    }
+    size_t o = nmoff[g] + blk;
+    nm[o] = nw;
+    t2[2 * o] = w0;
+    t2[2 * o + 1] = w1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Anchor index build.  Slot s of the batch holds the index of reference ref_ids[s].
+// ------------------------------------------------------------------------------------------
+struct IdxArgs {
+    GenomeTab G;
+    const u32* ref_ids;      // device, batch-relative
+    u32* dirz;               // slots * dir_stride
+    u32* ent;                // slots * ent_stride
+    u64 dir_stride, ent_stride;
+    int mal, mrd;
+    IndexGeom geo;
+};
+
+__device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, u32& bucket, u32& entry)
+{
+    u32 g = a.ref_ids[slot];
+    int T = ref_text_len(a.G.L[g], a.mrd);
+    if (p + a.mal > T) return false;
+    u64 o = a.G.nmoff[g];
+    TextView R{a.G.t2 + 2 * o, a.G.nm + o, T};
+    u64 key;
+    if (!kmer_at(R, p, a.mal, key)) return false;
+    IndexView iv;
+    iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
+    u32 tag;
+    key_slot(iv, key, bucket, tag);
+    entry = (tag << a.geo.posbits) | (u32)p;
+    return true;
+}
+
+__global__ void k_idx_count(IdxArgs a, int Tmax)
+{
+    u32 slot = blockIdx.y;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Tmax) return;
+    u32 b, e;
+    if (idx_slot_key(a, slot, p, b, e)) atomicAdd(&a.dirz[slot * a.dir_stride + 1 + b], 1u);
+}
+
+// In-place exclusive scan of the 2^dirbits bucket counts of one slot (one 1024-thread block).
+__global__ void __launch_bounds__(1024) k_idx_scan(u32* dirz, u64 dir_stride, u32 nb)
+{
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry_s;
+    u32* cnt = dirz + (u64)blockIdx.x * dir_stride + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 base = 0; base < nb; base += 1024) {
+        u32 idx = base + threadIdx.x;
+        u32 v = idx < nb ? cnt[idx] : 0;
+        u32 x = v;                                   // inclusive scan inside the wave
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        u32 woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        u32 carry = carry_s;
+        if (idx < nb) cnt[idx] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+}
+
+__global__ void k_idx_fill(IdxArgs a, int Tmax)
+{
+    u32 slot = blockIdx.y;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Tmax) return;
+    u32 b, e;
+    if (idx_slot_key(a, slot, p, b, e)) {
+        u32 at = atomicAdd(&a.dirz[slot * a.dir_stride + 1 + b], 1u);
+        a.ent[slot * a.ent_stride + at] = e;
+    }
+}
+
+// Ascending order inside every bucket (candidate order = ascending reference position per
+// k-mer, the order of the reference's probe chain).  Buckets hold ~1 entry.
+__global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, u32 nb)
+{
+    u32 slot = blockIdx.y;
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const u32* d = dirz + slot * dir_stride;
+    u32 s = d[b], e = d[b + 1];
+    u32* v = ent + slot * ent_stride;
+    for (u32 i = s + 1; i < e; ++i) {
+        u32 x = v[i];
+        u32 j = i;
+        while (j > s && v[j - 1] > x) { v[j] = v[j - 1]; --j; }
+        v[j] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pairs: the pair kernel.
+// ------------------------------------------------------------------------------------------
+struct DevWave {
+    const Params& P;
+    TextView R, Q;
+    IndexView I;
+    int lane;
+
+    __device__ __forceinline__ u64 mism_fwd(int q0, int r0, int n) const
+    {
+        bool mm = lane < n && !sym_match(R, r0 + lane, Q, q0 + lane);
+        return __ballot(mm);
+    }
+    __device__ __forceinline__ u64 mism_bwd(int q0, int r0, int n) const
+    {
+        bool mm = lane < n && !sym_match(R, r0 - 1 - lane, Q, q0 - 1 - lane);
+        return __ballot(mm);
+    }
+    __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit,
+                                               int& ev_lane, int& bpos, int& blen) const
+    {
+        int bp = 0, bl = 0;
+        if (lane < n)
+            eval_step(P, R, Q, I, i + lane, trk && (lit + lane <= P.mqd), r_end, lit + lane, bp, bl);
+        u64 hit = __ballot(lane < n && bl >= P.msl);
+        if (!hit) return false;
+        ev_lane = ctz64(hit);
+        bpos = __builtin_amdgcn_readlane(bp, ev_lane);     // ev_lane is wave-uniform (from the ballot)
+        blen = __builtin_amdgcn_readlane(bl, ev_lane);
+        return true;
+    }
+    __device__ __forceinline__ ExtMasks ext_scan(u64 prevB, u64 B, int n) const
+    {
+        bool b, q;
+        ext_lane(prevB, B, lane, n, P.aw, P.am, P.ar, b, q);
+        ExtMasks m;
+        m.brk = __ballot(b);
+        m.qual = __ballot(q);
+        return m;
+    }
+    __device__ __forceinline__ int best_split(u64 Lm, u64 Rm, int to_scan) const
+    {
+        // lane s scores split s; to_scan can be 64, so split 64 is scored by every lane too
+        int key = -1;
+        if (lane <= to_scan) key = (popc64(Lm & lowmask(lane)) + popc64(Rm >> lane)) * 128 + lane;
+        if (to_scan == 64) key = imax(key, popc64(Lm) * 128 + 64);
+        for (int d = 32; d >= 1; d >>= 1) key = imax(key, __shfl_xor(key, d));
+        return key & 127;
+    }
+};
+
+struct PairArgs {
+    GenomeTab G;
+    Params P;
+    IndexGeom geo;
+    const u32* dirz;
+    const u32* ent;
+    u64 dir_stride, ent_stride;
+    const u32* ref_ids;      // device, batch-relative rows
+    const u64* row_off;      // device, batch-relative rows (+1), absolute pair offsets
+    const u32* query_ids;    // device, absolute pair offsets, or nullptr for dense rows
+    u32 n_rows;
+    u64 e_begin, e_end;
+    int* out;                // 3 ints per pair, absolute pair offsets
+    unsigned long long* cursor;
+};
+
+__global__ void __launch_bounds__(256) k_pairs(PairArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        // One ticket per wave.  NB: this is the only lane-dependent branch of the persistent loop.
+        // A second `if (lane == 0)` at the loop tail (the result store) let the compiler thread the
+        // two branches across the back-edge and split lane 0 from lanes 1..63, which then spun on a
+        // dead lane's ticket; the store below is therefore done by every lane.
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(a.cursor, 1ULL);
+        const u32 tlo = __builtin_amdgcn_readfirstlane((u32)t);
+        const u32 thi = __builtin_amdgcn_readfirstlane((u32)(t >> 32));
+        const unsigned long long e = (((unsigned long long)thi << 32) | tlo) + a.e_begin;
+        if (e >= a.e_end) break;
+        // row of pair e: last k with row_off[k] <= e
+        u32 lo = 0, hi = a.n_rows;
+        while (hi - lo > 1) {
+            u32 mid = (lo + hi) >> 1;
+            if (a.row_off[mid] <= e) lo = mid; else hi = mid;
+        }
+        const u32 slot = lo;
+        const u32 r = a.ref_ids[slot];
+        u32 q;
+        if (a.query_ids) q = a.query_ids[e];
+        else { u32 j = (u32)(e - a.row_off[slot]); q = j + (j >= r ? 1u : 0u); }
+
+        const int Lr = a.G.L[r], Lq = a.G.L[q];
+        const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
+        const int T = ref_text_len(Lr, a.P.mrd), D = Lq + a.P.mrd;
+        IndexView iv;
+        iv.dirz = a.dirz + slot * a.dir_stride;
+        iv.ent = a.ent + slot * a.ent_stride;
+        iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
+        DevWave w{a.P, TextView{a.G.t2 + 2 * ro, a.G.nm + ro, T}, TextView{a.G.t2 + 2 * qo, a.G.nm + qo, D}, iv, lane};
+        PairMachine<DevWave> m(w, a.P, T, D);
+        int res[3];
+        m.run(res);
+        int* o = a.out + 3 * e;          // every lane stores the same wave-uniform values
+        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+    }
+}
+
+}  // namespace lzani
+
+// ============================================================================================
+// Host side of the C-ABI
+// ============================================================================================
+using namespace lzani;
+
+struct lzani_ctx {
+    Params P;
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+
+    u32 n = 0;
+    std::vector<int> L;
+    std::vector<u64> nmoff;
+    int Tmax = 0;
+    IndexGeom geo{};
+    u64* d_t2 = nullptr;
+    u64* d_nm = nullptr;
+    u64* d_nmoff = nullptr;
+    int* d_L = nullptr;
+
+    u32* d_dirz = nullptr;
+    u32* d_ent = nullptr;
+    u32 slots = 0;
+    u64 dir_stride = 0, ent_stride = 0;
+    unsigned long long* d_cursor = nullptr;
+
+    lzani_timing tm{};
+};
+
+namespace {
+
+bool trace_on()
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("LZANI_TRACE"); on = (e && *e && *e != '0') ? 1 : 0; }
+    return on == 1;
+}
+#define TRACE(...) do { if (trace_on()) { fprintf(stderr, "[lzani] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
+int fail(lzani_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                               \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(c, e_ == hipErrorOutOfMemory ? LZANI_ERR_NOMEM : LZANI_ERR_DEVICE,            \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                           \
+    } while (0)
+
+void free_genomes(lzani_ctx* c)
+{
+    hipFree(c->d_t2); hipFree(c->d_nm); hipFree(c->d_nmoff); hipFree(c->d_L);
+    c->d_t2 = c->d_nm = c->d_nmoff = nullptr; c->d_L = nullptr;
+    c->n = 0;
+}
+void free_slabs(lzani_ctx* c)
+{
+    hipFree(c->d_dirz); hipFree(c->d_ent);
+    c->d_dirz = c->d_ent = nullptr; c->slots = 0;
+}
+
+int ensure_slabs(lzani_ctx* c, u32 want_rows)
+{
+    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride);
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+    size_t have = c->slots * per_slot;
+    size_t budget = (size_t)((free_b + have) * 0.6);
+    u32 slots = (u32)std::min<size_t>(std::min<u32>(want_rows, 65535u), std::max<size_t>(1, budget / per_slot));  // gridDim.y limit
+    if (slots <= c->slots) return LZANI_OK;
+    free_slabs(c);
+    HIPCHK(c, hipMalloc(&c->d_dirz, (size_t)slots * c->dir_stride * 4));
+    HIPCHK(c, hipMalloc(&c->d_ent, (size_t)slots * c->ent_stride * 4));
+    c->slots = slots;
+    return LZANI_OK;
+}
+
+GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmoff, c->d_L}; }
+
+// Index build of `rows` references (device list d_ref_ids) into slots 0..rows-1.
+int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
+{
+    IdxArgs ia;
+    ia.G = gtab(c);
+    ia.ref_ids = d_ref_ids;
+    ia.dirz = c->d_dirz; ia.ent = c->d_ent;
+    ia.dir_stride = c->dir_stride; ia.ent_stride = c->ent_stride;
+    ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo;
+    const u32 nb = 1u << c->geo.dirbits;
+    HIPCHK(c, hipMemsetAsync(c->d_dirz, 0, (size_t)rows * c->dir_stride * 4, c->stream));
+    dim3 gp((c->Tmax + 255) / 256, rows);
+    hipLaunchKernelGGL(k_idx_count, gp, dim3(256), 0, c->stream, ia, c->Tmax);
+    hipLaunchKernelGGL(k_idx_scan, dim3(rows), dim3(1024), 0, c->stream, c->d_dirz, c->dir_stride, nb);
+    hipLaunchKernelGGL(k_idx_fill, gp, dim3(256), 0, c->stream, ia, c->Tmax);
+    hipLaunchKernelGGL(k_idx_sort, dim3((nb + 255) / 256, rows), dim3(256), 0, c->stream,
+                       c->d_dirz, c->d_ent, c->dir_stride, c->ent_stride, nb);
+    HIPCHK(c, hipGetLastError());
+    c->tm.index_launches += 4;
+    return LZANI_OK;
+}
+
+int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_off, const u32* query_ids,
+                  int* d_out)
+{
+    if (!c->n) return fail(c, LZANI_ERR_STATE, "lzani_run_rows: no genomes set");
+    c->tm = lzani_timing{};
+    if (n_rows == 0) return LZANI_OK;
+    const u64 n_pairs = row_off[n_rows];
+    for (u32 k = 0; k < n_rows; ++k) {
+        if (ref_ids[k] >= c->n) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: reference id out of range");
+        if (row_off[k + 1] < row_off[k]) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: row_off not monotone");
+        if (!query_ids && row_off[k + 1] - row_off[k] != (u64)c->n - 1)
+            return fail(c, LZANI_ERR_ARG, "lzani_run_rows: dense row must have n-1 queries");
+    }
+    if (row_off[0] != 0) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: row_off[0] must be 0");
+    if (query_ids)
+        for (u64 e = 0; e < n_pairs; ++e)
+            if (query_ids[e] >= c->n) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: query id out of range");
+    if (n_pairs == 0) return LZANI_OK;
+
+    HIPCHK(c, hipSetDevice(c->dev));
+    int rc = ensure_slabs(c, n_rows);
+    if (rc) return rc;
+
+    u32* d_ref = nullptr; u64* d_off = nullptr; u32* d_q = nullptr;
+    HIPCHK(c, hipMalloc(&d_ref, (size_t)n_rows * 4));
+    HIPCHK(c, hipMalloc(&d_off, (size_t)(n_rows + 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(d_ref, ref_ids, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_off, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (query_ids) {
+        HIPCHK(c, hipMalloc(&d_q, (size_t)n_pairs * 4));
+        HIPCHK(c, hipMemcpyAsync(d_q, query_ids, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    }
+
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->dev));
+    const u32 max_blocks = (u32)prop.multiProcessorCount * 8u;
+
+    for (u32 k0 = 0; k0 < n_rows; k0 += c->slots) {
+        u32 rows = std::min(c->slots, n_rows - k0);
+        u64 e0 = row_off[k0], e1 = row_off[k0 + rows];
+        TRACE("batch rows [%u,%u) pairs [%llu,%llu) slots=%u", k0, k0 + rows, (unsigned long long)e0, (unsigned long long)e1, c->slots);
+        HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        rc = build_indexes(c, d_ref + k0, rows);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        if (e1 > e0) {
+            PairArgs pa;
+            pa.G = gtab(c);
+            pa.P = c->P; pa.geo = c->geo;
+            pa.dirz = c->d_dirz; pa.ent = c->d_ent;
+            pa.dir_stride = c->dir_stride; pa.ent_stride = c->ent_stride;
+            pa.ref_ids = d_ref + k0; pa.row_off = d_off + k0; pa.query_ids = d_q;
+            pa.n_rows = rows; pa.e_begin = e0; pa.e_end = e1;
+            pa.out = d_out; pa.cursor = c->d_cursor;
+            HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, sizeof(unsigned long long), c->stream));
+            u64 waves = e1 - e0;
+            u32 blocks = (u32)std::min<u64>((waves + 3) / 4, max_blocks);
+            HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+            hipLaunchKernelGGL(k_pairs, dim3(blocks), dim3(256), 0, c->stream, pa);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            c->tm.pair_launches += 1;
+        }
+        if (trace_on()) { HIPCHK(c, hipEventSynchronize(c->ev[1])); TRACE("index built"); }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        TRACE("pairs done");
+        int trip = 0;
+        HIPCHK(c, hipMemcpyFromSymbol(&trip, HIP_SYMBOL(g_guard_trip), sizeof(int)));
+        if (trip) {
+            int zero = 0;
+            HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_guard_trip), &zero, sizeof(int)));
+            return fail(c, LZANI_ERR_DEVICE, "pair kernel: loop guard " + std::to_string(trip) + " tripped (corrupt index or text)");
+        }
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        c->tm.index_ms += ms;
+        if (e1 > e0) {
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+            c->tm.pairs_ms += ms;
+        }
+        c->tm.pairs += e1 - e0;
+    }
+    hipFree(d_ref); hipFree(d_off); hipFree(d_q);
+    return LZANI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void lzani_default_params(lzani_params* p)
+{
+    p->min_anchor_len = 11; p->min_seed_len = 7; p->max_dist_in_ref = 40; p->max_dist_in_query = 40;
+    p->min_region_len = 35; p->approx_window = 15; p->approx_mismatches = 7; p->approx_run_len = 3;
+}
+
+int lzani_create(const lzani_params* p, int device_id, lzani_ctx** out)
+{
+    if (!p || !out) return LZANI_ERR_ARG;
+    *out = nullptr;
+    Params P{p->min_anchor_len, p->min_seed_len, p->max_dist_in_ref, p->max_dist_in_query,
+             p->min_region_len, p->approx_window, p->approx_mismatches, p->approx_run_len};
+    if (!params_supported(P)) return LZANI_ERR_PARAMS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return LZANI_ERR_DEVICE;
+    lzani_ctx* c = new (std::nothrow) lzani_ctx();
+    if (!c) return LZANI_ERR_NOMEM;
+    c->P = P;
+    c->dev = device_id;
+    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
+              hipMalloc(&c->d_cursor, sizeof(unsigned long long)) == hipSuccess;
+    for (int k = 0; ok && k < 4; ++k) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
+    if (!ok) { lzani_destroy(c); return LZANI_ERR_DEVICE; }
+    *out = c;
+    return LZANI_OK;
+}
+
+void lzani_destroy(lzani_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->dev);
+    free_genomes(c);
+    free_slabs(c);
+    hipFree(c->d_cursor);
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* lzani_last_error(const lzani_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, const uint32_t* len)
+{
+    if (!c) return LZANI_ERR_ARG;
+    if (!n || !codes || !len) return fail(c, LZANI_ERR_ARG, "lzani_set_genomes: empty input");
+    HIPCHK(c, hipSetDevice(c->dev));
+    free_genomes(c);
+    free_slabs(c);
+    c->L.resize(n);
+    c->nmoff.resize(n);
+    std::vector<u64> codeoff(n);
+    u64 total_codes = 0, total_nm = 0;
+    int Lmax = 0;
+    for (u32 g = 0; g < n; ++g) {
+        if (len[g] > 0x3FFFFFFFu - 3u * (u32)c->P.mrd)
+            return fail(c, LZANI_ERR_ARG, "lzani_set_genomes: sequence too long for 32-bit text positions");
+        if (len[g] && !codes[g]) return fail(c, LZANI_ERR_ARG, "lzani_set_genomes: null sequence");
+        c->L[g] = (int)len[g];
+        Lmax = std::max(Lmax, c->L[g]);
+        codeoff[g] = total_codes; total_codes += len[g];
+        c->nmoff[g] = total_nm; total_nm += text_wordsN(ref_text_len(c->L[g], c->P.mrd));
+    }
+    c->Tmax = ref_text_len(Lmax, c->P.mrd);
+    c->geo = index_geometry(c->Tmax, c->P.mal);
+    c->dir_stride = ((u64)1 << c->geo.dirbits) + 1;
+    c->ent_stride = (u64)c->Tmax;
+
+    uint8_t* d_codes = nullptr; u64* d_codeoff = nullptr;
+    HIPCHK(c, hipMalloc(&d_codes, std::max<u64>(total_codes, 1)));
+    HIPCHK(c, hipMalloc(&d_codeoff, (size_t)n * 8));
+    HIPCHK(c, hipMalloc(&c->d_t2, total_nm * 16));
+    HIPCHK(c, hipMalloc(&c->d_nm, total_nm * 8));
+    HIPCHK(c, hipMalloc(&c->d_nmoff, (size_t)n * 8));
+    HIPCHK(c, hipMalloc(&c->d_L, (size_t)n * 4));
+    // stage the codes through one pinned-size host buffer per chunk of genomes
+    {
+        std::vector<uint8_t> stage;
+        const u64 chunk = 256ull << 20;
+        u32 g = 0;
+        while (g < n) {
+            u32 g1 = g; u64 bytes = 0;
+            while (g1 < n && (bytes == 0 || bytes + len[g1] <= chunk)) { bytes += len[g1]; ++g1; }
+            stage.resize(bytes);
+            u64 o = 0;
+            for (u32 k = g; k < g1; ++k) { if (len[k]) memcpy(stage.data() + o, codes[k], len[k]); o += len[k]; }
+            if (bytes) HIPCHK(c, hipMemcpy(d_codes + codeoff[g], stage.data(), bytes, hipMemcpyHostToDevice));
+            g = g1;
+        }
+    }
+    HIPCHK(c, hipMemcpy(d_codeoff, codeoff.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_nmoff, c->nmoff.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_L, c->L.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    c->n = n;
+    size_t maxblk = text_wordsN(c->Tmax);
+    // gridDim.y is limited to 65535: pack in slices of genomes
+    for (u32 g0 = 0; g0 < n; g0 += 32768) {
+        u32 cnt = std::min<u32>(32768, n - g0);
+        hipLaunchKernelGGL(k_pack, dim3((u32)((maxblk + 127) / 128), cnt), dim3(128), 0, c->stream,
+                           d_codes, d_codeoff + g0, c->d_t2, c->d_nm, c->d_nmoff + g0, c->d_L + g0, c->P.mrd, cnt);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    TRACE("set_genomes: n=%u Tmax=%d dirbits=%d posbits=%d tagmask=%x", n, c->Tmax, c->geo.dirbits, c->geo.posbits, c->geo.tagmask);
+    hipFree(d_codes); hipFree(d_codeoff);
+    return LZANI_OK;
+}
+
+int lzani_run_rows_device(lzani_ctx* c, uint32_t n_rows, const uint32_t* ref_ids, const uint64_t* row_off,
+                          const uint32_t* query_ids, void* d_out)
+{
+    if (!c) return LZANI_ERR_ARG;
+    if (!ref_ids || !row_off || (!d_out && n_rows && row_off[n_rows]))
+        return fail(c, LZANI_ERR_ARG, "lzani_run_rows_device: null argument");
+    return run_rows_impl(c, n_rows, ref_ids, row_off, query_ids, (int*)d_out);
+}
+
+int lzani_run_rows(lzani_ctx* c, uint32_t n_rows, const uint32_t* ref_ids, const uint64_t* row_off,
+                   const uint32_t* query_ids, lzani_result* out)
+{
+    if (!c) return LZANI_ERR_ARG;
+    if (!ref_ids || !row_off) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: null argument");
+    const u64 n_pairs = n_rows ? row_off[n_rows] : 0;
+    if (n_pairs && !out) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: null output");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int* d_out = nullptr;
+    if (n_pairs) HIPCHK(c, hipMalloc(&d_out, n_pairs * sizeof(lzani_result)));
+    int rc = run_rows_impl(c, n_rows, ref_ids, row_off, query_ids, d_out);
+    if (rc == LZANI_OK && n_pairs) {
+        hipError_t e = hipMemcpy(out, d_out, n_pairs * sizeof(lzani_result), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, LZANI_ERR_DEVICE, std::string("copy results: ") + hipGetErrorString(e));
+    }
+    hipFree(d_out);
+    return rc;
+}
+
+int lzani_get_timing(const lzani_ctx* c, lzani_timing* t)
+{
+    if (!c || !t) return LZANI_ERR_ARG;
+    *t = c->tm;
+    return LZANI_OK;
+}
+
+int lzani_debug_get_index(lzani_ctx* c, uint32_t id, uint64_t* t2, uint64_t* nm, uint32_t* dirz,
+                          uint32_t* ent, uint32_t* n_ent, uint32_t* geom)
+{
+    if (!c) return LZANI_ERR_ARG;
+    if (!c->n || id >= c->n) return fail(c, LZANI_ERR_ARG, "lzani_debug_get_index: bad id");
+    HIPCHK(c, hipSetDevice(c->dev));
+    int rc = ensure_slabs(c, 1);
+    if (rc) return rc;
+    u32* d_ref = nullptr;
+    HIPCHK(c, hipMalloc(&d_ref, 4));
+    HIPCHK(c, hipMemcpy(d_ref, &id, 4, hipMemcpyHostToDevice));
+    rc = build_indexes(c, d_ref, 1);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_ref);
+    int T = ref_text_len(c->L[id], c->P.mrd);
+    size_t wn = text_wordsN(T);
+    if (nm) HIPCHK(c, hipMemcpy(nm, c->d_nm + c->nmoff[id], wn * 8, hipMemcpyDeviceToHost));
+    if (t2) HIPCHK(c, hipMemcpy(t2, c->d_t2 + 2 * c->nmoff[id], wn * 16, hipMemcpyDeviceToHost));
+    std::vector<u32> d(c->dir_stride);
+    HIPCHK(c, hipMemcpy(d.data(), c->d_dirz, c->dir_stride * 4, hipMemcpyDeviceToHost));
+    u32 ne = d[c->dir_stride - 1];
+    if (dirz) memcpy(dirz, d.data(), c->dir_stride * 4);
+    if (ent && ne) HIPCHK(c, hipMemcpy(ent, c->d_ent, (size_t)ne * 4, hipMemcpyDeviceToHost));
+    if (n_ent) *n_ent = ne;
+    if (geom) { geom[0] = c->geo.kb; geom[1] = c->geo.dirbits; geom[2] = c->geo.posbits; geom[3] = c->geo.tagmask; }
+    return LZANI_OK;
+}
+
+}  // extern "C"

@@ -8,10 +8,11 @@ namespace lzani {
 // |R| = fwd + 2*mrd N + RC + mrd N   (parser.cpp:18-24)
 LZ_HD int ref_text_len(int L, int mrd) { return 2 * L + 3 * mrd; }
 
-// u64 words of the 2-bit text / the N mask of a T-symbol text.  Two spare words keep the
-// unaligned 128-bit window reads (win2/winN) in bounds; spare symbols are flagged N.
-LZ_HD size_t text_words2(int T) { return (size_t)((T + 31) >> 5) + 2; }
+// u64 words of the N mask / the 2-bit text of a T-symbol text: whole 64-symbol blocks (one
+// mask word + two text words each) plus two spare blocks that keep the unaligned 128-bit
+// window reads (win2/winN) in bounds; spare symbols are flagged N.
 LZ_HD size_t text_wordsN(int T) { return (size_t)((T + 63) >> 6) + 2; }
+LZ_HD size_t text_words2(int T) { return 2 * text_wordsN(T); }
 
 struct IndexGeom {
     int kb, dirbits, posbits;

@@ -1,0 +1,178 @@
+"""ctypes binding of the C-ABI in include/lzani.h (liblzani_hip.so).
+
+Used by the test-suite, bench.py and __graft_entry__.py.  It is deliberately thin: the product
+is the shared library; this module only marshals numpy arrays into the plain pointers and sizes
+the ABI takes.  There is no CPU fallback: if the HIP library is missing or a call fails, it raises.
+
+Interface mirror: `Engine` plays the role of the reference's CParser + the worker loop of
+CLZMatcher::do_matching (/root/reference/src/parser.h:237-253, lz_matcher.cpp:172-277):
+construct with the LZ parameters, hand over the sequences, run rows of (reference, queries).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "liblzani_hip.so")
+SRC = os.path.join(HERE, "csrc", "lzani_hip.hip")
+
+PARAM_ORDER = ("mal", "msl", "mrd", "mqd", "reg", "aw", "am", "ar")
+DEFAULT_PARAMS = dict(mal=11, msl=7, mrd=40, mqd=40, reg=35, aw=15, am=7, ar=3)
+
+ERRORS = {-1: "LZANI_ERR_ARG", -2: "LZANI_ERR_PARAMS", -3: "LZANI_ERR_DEVICE",
+          -4: "LZANI_ERR_STATE", -5: "LZANI_ERR_NOMEM"}
+
+EXPORTS = ("lzani_default_params", "lzani_create", "lzani_destroy", "lzani_last_error",
+           "lzani_set_genomes", "lzani_run_rows", "lzani_run_rows_device", "lzani_get_timing",
+           "lzani_debug_get_index")
+
+
+class LzaniError(RuntimeError):
+    pass
+
+
+class Timing(C.Structure):
+    _fields_ = [("index_ms", C.c_double), ("pairs_ms", C.c_double), ("pair_launches", C.c_uint32),
+                ("index_launches", C.c_uint32), ("pairs", C.c_uint64)]
+
+
+def build_library(force=False):
+    """hipcc cross-compiles for gfx950 without a GPU present."""
+    deps = [SRC, os.path.join(HERE, "csrc", "lzani_core.h"), os.path.join(HERE, "csrc", "lzani_layout.h"),
+            os.path.join(ROOT, "include", "lzani.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wno-unused-value", "-o", LIB_PATH, SRC]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LzaniError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback for the HIP path)")
+        lib = C.CDLL(LIB_PATH)
+        lib.lzani_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        lib.lzani_destroy.argtypes = [C.c_void_p]
+        lib.lzani_destroy.restype = None
+        lib.lzani_last_error.argtypes = [C.c_void_p]
+        lib.lzani_last_error.restype = C.c_char_p
+        lib.lzani_set_genomes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.lzani_run_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.lzani_run_rows_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.lzani_get_timing.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lzani_debug_get_index.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        _lib = lib
+    return _lib
+
+
+def params_array(params=None):
+    p = dict(DEFAULT_PARAMS)
+    if params:
+        p.update(params)
+    return (C.c_int32 * 8)(*[int(p[k]) for k in PARAM_ORDER]), p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def dense_rows(n, rows=None):
+    """CSR description of dense all2all rows (query_ids = None): ref_ids, row_off."""
+    ref_ids = np.arange(n, dtype=np.uint32) if rows is None else np.asarray(rows, dtype=np.uint32)
+    row_off = np.arange(len(ref_ids) + 1, dtype=np.uint64) * np.uint64(max(n - 1, 0))
+    return ref_ids, row_off
+
+
+class Engine:
+    def __init__(self, params=None, device=0):
+        self.lib = load_library()
+        arr, self.params = params_array(params)
+        h = C.c_void_p()
+        rc = self.lib.lzani_create(arr, int(device), C.byref(h))
+        if rc != 0:
+            raise LzaniError(f"lzani_create failed: {ERRORS.get(rc, rc)}")
+        self.h = h
+        self.n = 0
+        self.lens = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lzani_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.lzani_last_error(self.h)
+            raise LzaniError(f"{what}: {ERRORS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def set_genomes(self, seqs):
+        seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+        ptrs = (C.c_void_p * len(seqs))(*[s.ctypes.data for s in seqs])
+        lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+        self._check(self.lib.lzani_set_genomes(self.h, len(seqs), ptrs, _ptr(lens)), "lzani_set_genomes")
+        self.n = len(seqs)
+        self.lens = lens
+
+    def run_rows(self, ref_ids, row_off, query_ids=None):
+        ref_ids = np.ascontiguousarray(ref_ids, dtype=np.uint32)
+        row_off = np.ascontiguousarray(row_off, dtype=np.uint64)
+        q = None if query_ids is None else np.ascontiguousarray(query_ids, dtype=np.uint32)
+        n_pairs = int(row_off[-1]) if len(row_off) else 0
+        out = np.zeros((n_pairs, 3), dtype=np.int32)
+        self._check(self.lib.lzani_run_rows(self.h, len(ref_ids), _ptr(ref_ids), _ptr(row_off), _ptr(q), _ptr(out)),
+                    "lzani_run_rows")
+        return out
+
+    def run_rows_device(self, ref_ids, row_off, query_ids, d_out_ptr):
+        """Results stay on the GPU at raw device pointer d_out_ptr (3 int32 per pair)."""
+        ref_ids = np.ascontiguousarray(ref_ids, dtype=np.uint32)
+        row_off = np.ascontiguousarray(row_off, dtype=np.uint64)
+        q = None if query_ids is None else np.ascontiguousarray(query_ids, dtype=np.uint32)
+        self._check(self.lib.lzani_run_rows_device(self.h, len(ref_ids), _ptr(ref_ids), _ptr(row_off), _ptr(q),
+                                                   C.c_void_p(int(d_out_ptr))), "lzani_run_rows_device")
+
+    def all2all(self):
+        """int32[n, n, 3]: out[r, q] = parse(query=q, ref=r), diagonal zero."""
+        n = self.n
+        ref_ids, row_off = dense_rows(n)
+        flat = self.run_rows(ref_ids, row_off, None)
+        out = np.zeros((n, n, 3), dtype=np.int32)
+        out[~np.eye(n, dtype=bool)] = flat
+        return out
+
+    def timing(self):
+        t = Timing()
+        self._check(self.lib.lzani_get_timing(self.h, C.byref(t)), "lzani_get_timing")
+        return dict(index_ms=t.index_ms, pairs_ms=t.pairs_ms, pair_launches=t.pair_launches,
+                    index_launches=t.index_launches, pairs=t.pairs)
+
+    def debug_index(self, gid):
+        mrd = self.params["mrd"]
+        T = 2 * int(self.lens[gid]) + 3 * mrd
+        wn = (T + 63) // 64 + 2
+        geom = np.zeros(4, dtype=np.uint32)
+        self._check(self.lib.lzani_debug_get_index(self.h, gid, None, None, None, None, None, _ptr(geom)), "debug")
+        nm = np.zeros(wn, dtype=np.uint64)
+        t2 = np.zeros(2 * wn, dtype=np.uint64)
+        dirz = np.zeros((1 << int(geom[1])) + 1, dtype=np.uint32)
+        ent = np.zeros(T + 1, dtype=np.uint32)
+        n_ent = C.c_uint32(0)
+        self._check(self.lib.lzani_debug_get_index(self.h, gid, _ptr(t2), _ptr(nm), _ptr(dirz), _ptr(ent),
+                                                   C.byref(n_ent), _ptr(geom)), "debug")
+        return dict(t2=t2, nm=nm, dirz=dirz, ent=ent[:n_ent.value].copy(), geom=geom)
