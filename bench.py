@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- all2all ANI hot path on MI355X: directed genome pairs per second.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: under torch.distributed.run)
+prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[1]): synthetic viral genomes, ~40 kbp,
+families of 10 with 1-15 % divergence, default LZ parameters, dense all2all.  At N = 1 the set has
+1,000 genomes = 999,000 directed pairs per step.  At N > 1 the rows of the all2all (one row = one
+reference against every other genome) are sharded cyclically over the ranks, every rank keeps the
+whole packed genome set resident, and the per-pair results are gathered with one RCCL all_gather;
+the set grows as 1000*sqrt(N) genomes so that each GPU keeps ~10^6 pairs ("weak" scaling).
+
+A step = one pass of the hot path over the rank's rows: per-reference index build + pair kernel
+(+ the gather when N > 1), genomes already resident in HBM, results left in HBM.
+`roofline` is for the pair kernel (k_pairs): algorithmic bytes B_pair summed over the
+pairs of a launch, divided by the launch duration measured with HIP events on the engine's stream.
+`cpu_baseline` times the reference's own CParser (oracle/_ref, kind "reference"; falls back to the
+C restatement, kind "port") on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "lz-ani_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import lzani_ctypes as L  # noqa: E402
+import synth_genomes as SG  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(lens, ref_ids, params):
+    """Sum over the dense rows `ref_ids` of B_pair = ceil(Lq/4) + ceil((2Lr+3mrd)/4) + 4(Lq+mrd-mal+1) + 12."""
+    lens = lens.astype(np.int64)
+    n = len(lens)
+    mrd, mal = params["mrd"], params["mal"]
+    q_bytes = (lens + 3) // 4 + 4 * np.maximum(lens + mrd - mal + 1, 0) + 12
+    total_q = int(q_bytes.sum())
+    tot = 0
+    for r in ref_ids:
+        r = int(r)
+        tot += (n - 1) * int((2 * lens[r] + 3 * mrd + 3) // 4) + (total_q - int(q_bytes[r]))
+    return tot
+
+
+def cpu_baseline(seqs, params, sample):
+    """Reference CParser (or the C port) on the dense all2all of the first `sample` genomes."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    sub = seqs[:sample]
+    npairs = len(sub) * (len(sub) - 1)
+    if O.lib_ref() is not None:
+        kind = "reference"
+        t = time.perf_counter()
+        res = O.ref_all2all(sub, params, threads=cores)
+        dt = time.perf_counter() - t
+    else:
+        kind = "port"
+        t = time.perf_counter()
+        res = O.oracle_all2all(sub, params, threads=cores)
+        dt = time.perf_counter() - t
+    return dict(value=npairs / dt, unit="genome-pairs/s", cores=cores, kind=kind,
+                sample=f"dense all2all of the first {len(sub)} genomes of the workload ({npairs} pairs, {dt:.2f} s wall, "
+                       f"{cores} threads self-scheduling over reference rows as in do_matching)"), res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genomes", type=int, default=0, help="0 = 1000*sqrt(gpus)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=128, help="genomes in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.genomes or int(round(1000 * math.sqrt(max(world, 1))))
+    names, seqs = SG.make_set(n, args.seed)
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    # reference order: length-descending, then name (CSeqReservoir::reorder_items, seq_reservoir.cpp:215-251)
+    order = sorted(range(n), key=lambda i: (-int(lens[i]), names[i]))
+    seqs = [seqs[i] for i in order]
+    lens = lens[order]
+
+    eng = L.Engine(None, device=local_rank)
+    params = eng.params
+    eng.set_genomes(seqs)                      # untimed: genomes resident in HBM before the timed region
+
+    my_rows = np.arange(rank, n, world, dtype=np.uint32)          # cyclic row shard
+    ref_ids, row_off = L.dense_rows(n, my_rows)
+    my_pairs = int(row_off[-1])
+    max_rows = (n + world - 1) // world
+    shard = torch.zeros(max_rows * (n - 1) * 3, dtype=torch.int32, device="cuda")
+    gathered = torch.zeros(world * shard.numel(), dtype=torch.int32, device="cuda") if world > 1 else None
+
+    def step():
+        eng.run_rows_device(ref_ids, row_off, None, shard.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, shard)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms, index_ms = 0.0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = eng.timing()
+        kernel_ms += tm["pairs_ms"]
+        index_ms += tm["index_ms"]
+        launches = tm["pair_launches"]
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    total_pairs = n * (n - 1)
+    out = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_pairs * args.steps / dt
+        abytes = algorithmic_bytes(lens, my_rows, params)        # rank 0's launches
+        avg_launch_ms = kernel_ms / max(1, args.steps * launches)
+        achieved = abytes / launches / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        out = {
+            "metric": "genome-pairs/sec + achieved HBM GB/s, 10k×40kbp all2all at 1/2/4/8 GPUs",
+            "value": value, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (2-bit packed symbols, 64-bit lane masks; f64 only in the anchor/seed arbitration)",
+            "data": "synthetic",
+            "config": {"workload": f"{n} synthetic ~40 kbp viral genomes (families of 10, 1-15% divergence, seed {args.seed}), "
+                                   f"dense all2all, default LZ params, {total_pairs} directed pairs/step",
+                       "genomes": n, "pairs_per_step": total_pairs, "pairs_per_gpu": my_pairs,
+                       "sharding": "reference rows cyclic over ranks, genomes replicated, one RCCL all_gather of int32[3] per pair"
+                                   if world > 1 else "single GPU, all rows",
+                       "params": params},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_pairs", "avg_launch_ms": avg_launch_ms, "launches_per_step": launches,
+                         "algorithmic_bytes_per_launch": abytes / launches,
+                         "index_build_ms_per_step": index_ms / args.steps},
+        }
+        if world == 1 and args.cpu_sample > 1:
+            cb, cpu_res = cpu_baseline(seqs, params, min(args.cpu_sample, n))
+            out["cpu_baseline"] = cb
+            # free parity evidence: the sampled pairs, GPU vs CPU
+            m = cpu_res.shape[0]
+            got = shard.cpu().numpy()[: my_pairs * 3].reshape(n, n - 1, 3)
+            ok = True
+            for r in range(m):
+                qs = [q for q in range(m) if q != r]
+                cols = [q if q < r else q - 1 for q in qs]
+                ok &= bool(np.array_equal(got[r, cols], cpu_res[r, qs]))
+            out["cpu_baseline"]["parity_on_sample"] = "bit-exact" if ok else "MISMATCH"
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if (out is None or not out.get("cpu_baseline") or out["cpu_baseline"].get("parity_on_sample") != "MISMATCH") else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

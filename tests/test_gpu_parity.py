@@ -1,0 +1,175 @@
+"""GPU: parity of the HIP path (through the C-ABI) with the oracle and the committed golden vectors.
+Bit-exact for every integer; the derived doubles are then byte-equal in the TSV."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lzani_ctypes as L
+import oracle as O
+import synth_genomes as SG
+import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_all2all(seqs, params=None):
+    eng = L.Engine(params)
+    try:
+        eng.set_genomes(seqs)
+        return eng.all2all()
+    finally:
+        eng.close()
+
+
+@pytest.fixture(scope="module")
+def vectors():
+    with open(os.path.join(U.GOLD, "ref_vectors.json")) as f:
+        return json.load(f)
+
+
+def _inputs(setname):
+    return {"example": lambda: U.load_example()[1], "edge": U.edge_set, "vir61": lambda: U.load_vir61()[1],
+            "synth24": lambda: SG.make_set(24, 11, lmin=6000, lmax=9000, fam=6)[1]}[setname]()
+
+
+def test_reference_vectors_through_c_abi(vectors):
+    """Every committed vector of the reference's CParser: example, edge set, synth24 under 12 parameter
+    sets, vir61 (3,660 pairs) under defaults."""
+    for key, item in vectors["sets"].items():
+        got = gpu_all2all(_inputs(key.split("/")[0]), item["params"])
+        want = np.array(item["res"], dtype=np.int32)
+        bad = np.argwhere((got != want).any(axis=2))
+        assert len(bad) == 0, f"{key}: {len(bad)} pairs differ, first {bad[:3].tolist()}: {got[tuple(bad[0])]} vs {want[tuple(bad[0])]}"
+
+
+def test_vir61_golden_tsv_from_gpu_results():
+    """BASELINE config 1 end to end on the GPU numbers: byte-identical to test/vir61.ani.tsv."""
+    names, seqs = U.reorder(*U.load_vir61())
+    res = gpu_all2all(seqs)
+    txt = U.emit_tsv(names, [len(s) for s in seqs], res, U.STANDARD)
+    assert txt == open(os.path.join(U.GOLD, "vir61.ani.tsv")).read()
+
+
+def test_device_built_text_and_index_match_model():
+    """k_pack and the k_idx_* kernels produce exactly the layout the host model builds."""
+    _, seqs = U.load_example()
+    seqs = seqs[:3] + [U.edge_set()[3], U.edge_set()[11]]
+    lib = U.model_lib()
+    for prm in (None, dict(mal=15, msl=9), dict(mal=5, msl=4)):
+        eng = L.Engine(prm)
+        eng.set_genomes(seqs)
+        maxlen = max(len(s) for s in seqs)
+        for gid, s in enumerate(seqs):
+            d = eng.debug_index(gid)
+            T = 2 * len(s) + 3 * eng.params["mrd"]
+            wn = (T + 63) // 64 + 2
+            t2 = np.zeros(2 * wn, np.uint64); nm = np.zeros(wn, np.uint64)
+            dirz = np.zeros(len(d["dirz"]), np.uint32); ent = np.zeros(T + 1, np.uint32)
+            n_ent = C.c_uint32(0)
+            s = np.ascontiguousarray(s)
+            assert lib.model_index(O._ptr(s), len(s), maxlen, O.params_array(prm), O._ptr(t2), O._ptr(nm),
+                                   O._ptr(dirz), O._ptr(ent), C.byref(n_ent)) == 0
+            assert np.array_equal(d["t2"], t2) and np.array_equal(d["nm"], nm)
+            assert np.array_equal(d["dirz"], dirz)
+            assert n_ent.value == len(d["ent"]) and np.array_equal(d["ent"], ent[:n_ent.value])
+        eng.close()
+
+
+def test_sparse_rows_ragged_and_empty():
+    """The filtered form of do_matching (lz_matcher.cpp:234-250): CSR rows with arbitrary query lists,
+    including empty rows, repeated references and unsorted queries."""
+    _, seqs = SG.make_set(20, 4, lmin=3000, lmax=6000, fam=5)
+    want = O.oracle_all2all(seqs, None, threads=8)
+    st = SG.Stream(99)
+    ref_ids, row_off, q = [], [0], []
+    for k in range(17):
+        r = st.randint(0, 19)
+        cnt = 0 if k % 5 == 2 else st.randint(1, 12)
+        ref_ids.append(r)
+        for _ in range(cnt):
+            x = st.randint(0, 19)
+            q.append(x if x != r else (x + 1) % 20)
+        row_off.append(len(q))
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    got = eng.run_rows(ref_ids, row_off, q)
+    eng.close()
+    k = 0
+    for row, r in enumerate(ref_ids):
+        for e in range(row_off[row], row_off[row + 1]):
+            assert got[e].tolist() == want[r, q[e]].tolist(), (row, r, q[e])
+            k += 1
+    assert k == len(q)
+
+
+def test_row_shards_equal_full_run_and_are_idempotent():
+    _, seqs = SG.make_set(30, 8, lmin=3000, lmax=5000, fam=6)
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    full = eng.all2all()
+    again = eng.all2all()
+    assert np.array_equal(full, again)
+    n = len(seqs)
+    for world in (2, 3):
+        merged = np.zeros_like(full)
+        for rank in range(world):
+            rows = np.arange(rank, n, world, dtype=np.uint32)
+            ref_ids, row_off = L.dense_rows(n, rows)
+            flat = eng.run_rows(ref_ids, row_off, None).reshape(len(rows), n - 1, 3)
+            for i, r in enumerate(rows):
+                merged[r, np.arange(n) != r] = flat[i]
+        assert np.array_equal(merged, full)
+    eng.close()
+
+
+def test_error_conventions():
+    eng = L.Engine()
+    with pytest.raises(L.LzaniError, match="LZANI_ERR_STATE"):
+        eng.run_rows([0], [0, 0], None)
+    seqs = U.edge_set()[:4]
+    eng.set_genomes(seqs)
+    with pytest.raises(L.LzaniError, match="LZANI_ERR_ARG"):
+        eng.run_rows([9], [0, 3], None)                       # reference id out of range
+    with pytest.raises(L.LzaniError, match="LZANI_ERR_ARG"):
+        eng.run_rows([0], [0, 2], None)                       # dense row must have n-1 queries
+    with pytest.raises(L.LzaniError, match="LZANI_ERR_ARG"):
+        eng.run_rows([0], [0, 1], [7])                        # query id out of range
+    assert eng.run_rows([], [0], None).shape == (0, 3)
+    eng.close()
+    with pytest.raises(L.LzaniError, match="LZANI_ERR_PARAMS"):
+        L.Engine(dict(mqd=100))
+
+
+def test_full_size_properties_1000_genomes():
+    """BASELINE configs[1] at full size (1,000 x ~40 kbp, 999,000 directed pairs): size-independent
+    properties on every pair plus exact agreement with the oracle on a seeded sample of pairs."""
+    names, seqs = SG.make_set(1000, 1)
+    lens = np.array([len(s) for s in seqs])
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    res = eng.all2all()
+    eng.close()
+    mat, lit, comp = res[..., 0], res[..., 1], res[..., 2]
+    assert (res >= 0).all()
+    assert ((comp == 0) == ((mat == 0) & (lit == 0)))[~np.eye(1000, dtype=bool)].all()
+    # a region needs >= reg symbols and cannot cover more than the query text
+    assert (mat + lit >= 35 * comp).all()
+    assert (mat + lit <= lens[None, :] + 40).all()
+    # family structure: a genome shares most of its length with its own ancestor (member 0)
+    fam0 = (np.arange(1000) // 10) * 10
+    idx = np.arange(1000)
+    rel = idx != fam0
+    assert (mat[fam0[rel], idx[rel]] > 0.5 * lens[idx[rel]]).all()
+    # unrelated random genomes share only chance matches (a few per cent at mal 11)
+    other = (idx + 500) % 1000
+    assert (mat[other, idx] < 0.05 * lens).all()
+    # checksum of checksums is reproducible and matches the oracle on a seeded sample
+    st = SG.Stream(123)
+    pairs = [(st.randint(0, 999), st.randint(0, 999)) for _ in range(400)]
+    pairs += [(10 * (k % 100), 10 * (k % 100) + 1 + k % 9) for k in range(200)]     # related pairs
+    for r, q in pairs:
+        if r != q:
+            assert tuple(res[r, q]) == O.oracle_pair(seqs[r], seqs[q]), (r, q)

@@ -1,0 +1,168 @@
+"""Shared helpers of the test-suite: fixture loading, seeded edge cases, the TSV emit rule."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+
+import oracle as O
+import synth_genomes as SG
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+VARIANTS = {
+    "default": {},
+    "long": dict(mal=15, msl=9, reg=60),                  # BASELINE config 4 parameters
+    "mrd20_mqd60": dict(mrd=20, mqd=60),
+    "aw10_am3_ar5": dict(aw=10, am=3, ar=5),
+    "short": dict(mrd=10, mqd=10, mal=9, msl=5, reg=20),
+}
+
+
+def load_example():
+    recs = O.read_multifasta(os.path.join(GOLD, "example", "multifasta.fna"))
+    return [r[0] for r in recs], [r[1] for r in recs]
+
+
+def load_vir61():
+    """--in-dir semantics: files sorted by name, every '>' record one item (multisample default)."""
+    names, seqs = [], []
+    for f in sorted(glob.glob(os.path.join(GOLD, "vir61", "*.fna"))):
+        for nm, s in O.read_multifasta(f):
+            names.append(nm)
+            seqs.append(s)
+    return names, seqs
+
+
+def reorder(names, seqs):
+    """CSeqReservoir::reorder_items (seq_reservoir.cpp:215-251): (len - 2*no_parts) as uint32, descending,
+    then name ascending (bytewise); stable."""
+    key = [((len(s) - 2) & 0xFFFFFFFF) for s in seqs]
+    order = sorted(range(len(seqs)), key=lambda i: (-key[i], names[i].encode()))
+    return [names[i] for i in order], [seqs[i] for i in order]
+
+
+def edge_set():
+    """Seeded corner cases: copies, reverse complement, N runs, SNPs, tiny and empty inputs, repeats."""
+    st = SG.Stream(5)
+    base = (st.u64(3000) % np.uint64(4)).astype(np.uint8)
+    rc = (3 - base[::-1]).astype(np.uint8)
+    snp = base.copy()
+    snp[::50] = (snp[::50] + 1) % 4
+    nins = np.concatenate([base[:1500], np.full(50, 5, np.uint8), base[1500:]])
+    mosaic = np.concatenate([base[100:900], rc[1000:2000], base[2100:2500]])
+    return [base, base.copy(), rc, nins, snp, base[:1500].copy(), np.full(200, 5, np.uint8),
+            base[:12].copy(), base[:5].copy(), np.zeros(0, np.uint8), np.zeros(500, np.uint8),
+            np.tile(np.array([0, 1], np.uint8), 400), mosaic,
+            np.concatenate([np.full(3, 5, np.uint8), base[:700], np.full(1, 5, np.uint8), base[700:1400]])]
+
+
+# ---- the reference's number formatting and TSV emit rule (lz_matcher.cpp:280-579,
+# ---- numeric_conversions.h:228-300), restated for the tests -------------------------------
+def real_to_str(v, prec):
+    if v == 0:
+        return "0"
+    r = repr(float(v))
+    mant, _, ex = r.partition("e")
+    exp10 = int(ex) if ex else 0
+    if "." in mant:
+        ip, fp = mant.split(".")
+    else:
+        ip, fp = mant, ""
+    digits = (ip + fp).lstrip("0")
+    exp10 -= len(fp)
+    lead_stripped = len(ip + fp) - len((ip + fp).lstrip("0"))
+    del lead_stripped
+    t = digits.rstrip("0")
+    exp10 += len(digits) - len(t)
+    sig = int(t)
+    nd = len(t)
+    if nd > prec:
+        p10 = 10 ** (nd - prec)
+        sig = (sig + p10 // 2) // p10
+        exp10 += nd - prec
+        nd = prec
+        if sig >= 10 ** prec:
+            sig //= 10
+            exp10 += 1
+    s = str(sig)
+    if exp10 == 0:
+        return s
+    if exp10 > 0 or -exp10 >= nd + 4:
+        e = exp10
+        if nd == 1:
+            out = s
+        else:
+            out = s[0] + "." + s[1:]
+            e += nd - 1
+        return out + ("e-%02d" % -e if e < 0 else "e+%02d" % e)
+    if -exp10 < nd:
+        k = nd + exp10
+        return s[:k] + "." + s[k:]
+    return "0." + "0" * (-exp10 - nd) + s
+
+
+def emit_tsv(names, lens, res, columns, in_percent=False):
+    """store_results for dense results res[r, q] (ids already in reordered order)."""
+    mult = 100.0 if in_percent else 1.0
+    lines = ["\t".join(columns)]
+    n = len(names)
+    for a in range(n):
+        for b in range(a + 1, n):
+            X = res[a, b]   # parse(query=b, ref=a)
+            Y = res[b, a]   # parse(query=a, ref=b)
+            ids = (a, b)
+            ln = (lens[b], lens[a])
+            mat = (int(X[0]), int(Y[0]))
+            lit = (int(X[1]), int(Y[1]))
+            reg = (int(X[2]), int(Y[2]))
+            tani = (mat[0] + mat[1]) / (ln[0] + ln[1])
+            gani = (mat[0] / ln[0], mat[1] / ln[1])
+            ani = tuple(m / (m + l) if m + l else 0.0 for m, l in zip(mat, lit))
+            cov = ((mat[0] + lit[0]) / ln[0], (mat[1] + lit[1]) / ln[1])
+            for i in (0, 1):
+                j = 1 - i
+                f = {"ridx": str(ids[i]), "qidx": str(ids[j]), "reference": names[ids[i]], "query": names[ids[j]],
+                     "qcov": real_to_str(mult * cov[i], 6), "rcov": real_to_str(mult * cov[j], 6),
+                     "gani": real_to_str(mult * gani[i], 6), "ani": real_to_str(mult * ani[i], 6),
+                     "tani": real_to_str(mult * tani, 6), "rlen": str(ln[j]), "qlen": str(ln[i]),
+                     "num_alns": str(reg[i]), "nt_match": str(mat[i]), "nt_mismatch": str(lit[i])}
+                if ln[0] and ln[1]:
+                    f["len_ratio"] = real_to_str(min(ln[i], ln[j]) / max(ln[i], ln[j]), 4)
+                else:
+                    f["len_ratio"] = "0"
+                lines.append("\t".join(f[c] for c in columns))
+    return "\n".join(lines) + "\n"
+
+
+STANDARD = "qidx,ridx,query,reference,tani,gani,ani,qcov,num_alns,len_ratio".split(",")
+
+
+# ---- the lane-emulating host model of the kernels (tests/model) --------------------------
+_model = None
+
+
+def model_lib():
+    global _model
+    if _model is None:
+        d = os.path.join(ROOT, "tests", "model")
+        so = os.path.join(d, "liblzani_model.so")
+        src = os.path.join(d, "lzani_model.cpp")
+        hdrs = [os.path.join(ROOT, "lz-ani_amd", "csrc", h) for h in ("lzani_core.h", "lzani_layout.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in [src] + hdrs):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so])
+        _model = C.CDLL(so)
+    return _model
+
+
+def model_all2all(seqs, params=None):
+    lib = model_lib()
+    seqs, ptrs, lens = O._seq_table(seqs)
+    n = len(seqs)
+    out = np.zeros((n, n, 3), dtype=np.int32)
+    rc = lib.model_all2all(n, ptrs, O._ptr(lens), O.params_array(params), O._ptr(out))
+    if rc != 0:
+        raise ValueError("model: unsupported parameters")
+    return out
