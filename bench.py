@@ -51,15 +51,28 @@ def algorithmic_bytes(lens, ref_ids, params):
     return tot
 
 
-def cpu_baseline(seqs, params, sample):
-    """Reference CParser (or the C port) on the dense all2all of the first `sample` genomes."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(math.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_baseline(seqs, params, sample):
+    """Reference CParser (or the C port) on the dense all2all of the first `sample` genomes."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    cores = host_cores()
     sub = seqs[:sample]
     npairs = len(sub) * (len(sub) - 1)
     if O.lib_ref() is not None:
