@@ -32,6 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "lz-ani_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import lzani_ctypes as L  # noqa: E402
+import shard as SH  # noqa: E402
 import synth_genomes as SG  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
@@ -127,11 +128,10 @@ def main():
     params = eng.params
     eng.set_genomes(seqs)                      # untimed: genomes resident in HBM before the timed region
 
-    my_rows = np.arange(rank, n, world, dtype=np.uint32)          # cyclic row shard
+    my_rows = SH.row_shard(n, rank, world)                        # cyclic row shard
     ref_ids, row_off = L.dense_rows(n, my_rows)
     my_pairs = int(row_off[-1])
-    max_rows = (n + world - 1) // world
-    shard = torch.zeros(max_rows * (n - 1) * 3, dtype=torch.int32, device="cuda")
+    shard = torch.zeros(SH.shard_len(n, world), dtype=torch.int32, device="cuda")
     gathered = torch.zeros(world * shard.numel(), dtype=torch.int32, device="cuda") if world > 1 else None
 
     def step():
