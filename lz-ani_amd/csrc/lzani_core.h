@@ -247,34 +247,42 @@ LZ_HD void arbitrate(const Params& P, int T, int lit, int ap, int al, int& sp, i
     if (anchor_prob > close_prob) { sp = ap; sl = al; }
 }
 
+// Close-seed search of one tracking step, portable form (parser.cpp:548-580): every window
+// position p in [r_end, ref_pred + mrd) whose msl-mer equals the query's, ascending.
+LZ_HD void seed_search_window(const Params& P, const TextView& R, const TextView& Q,
+                              int qp, int r_end, int lit, int& sp, int& sl)
+{
+    sp = 0; sl = 0;
+    u64 qk;
+    if (!kmer_at(Q, qp, P.msl, qk)) return;
+    int ref_pred = r_end + lit;
+    int hi = imin(ref_pred + P.mrd, R.len - P.msl + 1);
+    const int step = 33 - P.msl;             // window positions served by one 32-symbol load
+    const u64 km = lowmask(2 * P.msl), nk = lowmask(P.msl);
+    for (int p0 = r_end; p0 < hi; p0 += step) {
+        u64 w2 = win2(R.t2, p0), wn = winN(R.nm, p0);
+        int cnt = imin(step, hi - p0);
+        for (int o = 0; o < cnt; ++o) {
+            if (((w2 >> (2 * o)) & km) != qk || ((wn >> o) & nk)) continue;
+            seed_consider(p0 + o, equal_len(R, p0 + o, Q, qp, P.msl), ref_pred, sp, sl);
+        }
+    }
+}
+
 // One scan step evaluated in isolation (what one lane does in a round).
 //   trk   : the step starts in tracking mode (ref_pred >= 0)
 //   r_end : reference end of the last match (= ref_pred - lit)
 //   lit   : literal run length at the start of this step
-// Portable version of the close-seed search (window scan); the HIP wave uses a shared-window
-// variant with the same candidate order (lzani_kernels.hip).
+// The HIP wave replaces the per-lane window scan by a shared LDS join with the same candidate
+// order (lzani_hip.hip, DevWave::find_event).
 LZ_HD void eval_step(const Params& P, const TextView& R, const TextView& Q, const IndexView& I,
                      int qp, bool trk, int r_end, int lit, int& bp, int& bl)
 {
     int ap, al;
     best_anchor(P, R, Q, I, qp, ap, al);
     if (!trk) { bp = ap; bl = al; return; }
-    int sp = 0, sl = 0;
-    u64 qk;
-    if (kmer_at(Q, qp, P.msl, qk)) {
-        int ref_pred = r_end + lit;
-        int hi = imin(ref_pred + P.mrd, R.len - P.msl + 1);
-        const int step = 33 - P.msl;             // window positions served by one 32-symbol load
-        const u64 km = lowmask(2 * P.msl), nk = lowmask(P.msl);
-        for (int p0 = r_end; p0 < hi; p0 += step) {
-            u64 w2 = win2(R.t2, p0), wn = winN(R.nm, p0);
-            int cnt = imin(step, hi - p0);
-            for (int o = 0; o < cnt; ++o) {
-                if (((w2 >> (2 * o)) & km) != qk || ((wn >> o) & nk)) continue;
-                seed_consider(p0 + o, equal_len(R, p0 + o, Q, qp, P.msl), ref_pred, sp, sl);
-            }
-        }
-    }
+    int sp, sl;
+    seed_search_window(P, R, Q, qp, r_end, lit, sp, sl);
     arbitrate(P, R.len, lit, ap, al, sp, sl);
     bp = sp; bl = sl;
 }

@@ -171,11 +171,16 @@ __global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, 
 // ------------------------------------------------------------------------------------------
 // k_pairs: the pair kernel.
 // ------------------------------------------------------------------------------------------
+enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS };
+
 struct DevWave {
     const Params& P;
     TextView R, Q;
     IndexView I;
     int lane;
+    u32* heads;      // per-wave LDS: SEED_SLOTS chain heads
+    u32* nexts;      // 128 chain links
+    u32* keys;       // 128 window msl-mers
 
     __device__ __forceinline__ u64 mism_fwd(int q0, int r0, int n) const
     {
@@ -187,12 +192,71 @@ struct DevWave {
         bool mm = lane < n && !sym_match(R, r0 - 1 - lane, Q, q0 - 1 - lane);
         return __ballot(mm);
     }
+    // Close-seed search of all tracking lanes of a round at once.  The <= 128 window positions
+    // [r_end, r_end + W) are hashed by their msl-mer into a per-wave LDS table (two lanes-passes),
+    // every tracking lane then walks the one chain of its own msl-mer and collects the matching
+    // positions below its own window limit into a 128-bit mask; candidates are taken in ascending
+    // position, which is the order of the reference's ht_short bucket (parser.cpp:555-579).
+    __device__ __forceinline__ void seed_join(int i, int nt, int r_end, int lit, int W, int& sp, int& sl) const
+    {
+        sp = 0; sl = 0;
+        const u32 EMPTY = 0xFFFFFFFFu;
+        for (int k = 0; k < SEED_SLOTS / 64; ++k) heads[lane + 64 * k] = EMPTY;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int pass = 0; pass < 2; ++pass) {
+            int idx = lane + 64 * pass;
+            u64 rk;
+            if (idx < W && kmer_at(R, r_end + idx, P.msl, rk)) {
+                u32 slot = ((u32)rk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS);
+                keys[idx] = (u32)rk;
+                nexts[idx] = atomicExch(&heads[slot], (u32)idx);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u64 qk;
+        if (lane < nt && kmer_at(Q, i + lane, P.msl, qk)) {
+            const u32 lim = (u32)(lit + lane + P.mrd);          // this step's window is [0, lim)
+            u64 c0 = 0, c1 = 0;
+            u32 slot = ((u32)qk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS);
+            int guard = 0;
+            for (u32 h = heads[slot]; h != EMPTY; h = nexts[h]) {
+                if (++guard > 128) { LZ_GUARD_TRIP(4); break; }
+                if (keys[h] == (u32)qk && h < lim) {
+                    if (h < 64) c0 |= 1ULL << h; else c1 |= 1ULL << (h - 64);
+                }
+            }
+            const int ref_pred = r_end + lit + lane;
+            while (c0) {
+                int idx = ctz64(c0); c0 &= c0 - 1;
+                seed_consider(r_end + idx, equal_len(R, r_end + idx, Q, i + lane, P.msl), ref_pred, sp, sl);
+            }
+            while (c1) {
+                int idx = 64 + ctz64(c1); c1 &= c1 - 1;
+                seed_consider(r_end + idx, equal_len(R, r_end + idx, Q, i + lane, P.msl), ref_pred, sp, sl);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
     __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit,
                                                int& ev_lane, int& bpos, int& blen) const
     {
         int bp = 0, bl = 0;
-        if (lane < n)
-            eval_step(P, R, Q, I, i + lane, trk && (lit + lane <= P.mqd), r_end, lit + lane, bp, bl);
+        if (lane < n) best_anchor(P, R, Q, I, i + lane, bp, bl);
+        const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
+        if (nt > 0) {                                                // wave-uniform
+            int sp = 0, sl = 0;
+            const int W = imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end);
+            if (W > 128 || P.msl > 16) {
+                if (lane < nt) seed_search_window(P, R, Q, i + lane, r_end, lit + lane, sp, sl);
+            } else if (W > 0) seed_join(i, nt, r_end, lit, W, sp, sl);
+            if (lane < nt) {
+                arbitrate(P, R.len, lit + lane, bp, bl, sp, sl);
+                bp = sp; bl = sl;
+            }
+        }
         u64 hit = __ballot(lane < n && bl >= P.msl);
         if (!hit) return false;
         ev_lane = ctz64(hit);
@@ -239,6 +303,8 @@ struct PairArgs {
 __global__ void __launch_bounds__(256) k_pairs(PairArgs a)
 {
     const int lane = threadIdx.x & 63;
+    __shared__ u32 s_seed[4][SEED_SLOTS + 256];
+    u32* const lds = s_seed[threadIdx.x >> 6];
     for (;;) {
         // One ticket per wave.  NB: this is the only lane-dependent branch of the persistent loop.
         // A second `if (lane == 0)` at the loop tail (the result store) let the compiler thread the
@@ -269,7 +335,8 @@ __global__ void __launch_bounds__(256) k_pairs(PairArgs a)
         iv.dirz = a.dirz + slot * a.dir_stride;
         iv.ent = a.ent + slot * a.ent_stride;
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
-        DevWave w{a.P, TextView{a.G.t2 + 2 * ro, a.G.nm + ro, T}, TextView{a.G.t2 + 2 * qo, a.G.nm + qo, D}, iv, lane};
+        DevWave w{a.P, TextView{a.G.t2 + 2 * ro, a.G.nm + ro, T}, TextView{a.G.t2 + 2 * qo, a.G.nm + qo, D}, iv, lane,
+                  lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128};
         PairMachine<DevWave> m(w, a.P, T, D);
         int res[3];
         m.run(res);
