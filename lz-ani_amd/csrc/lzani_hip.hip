@@ -171,7 +171,7 @@ __global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, 
 // ------------------------------------------------------------------------------------------
 // k_pairs: the pair kernel.
 // ------------------------------------------------------------------------------------------
-enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS };
+enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS, NQUEUES = 8 };
 
 struct DevWave {
     const Params& P;
@@ -294,39 +294,56 @@ struct PairArgs {
     const u32* ref_ids;      // device, batch-relative rows
     const u64* row_off;      // device, batch-relative rows (+1), absolute pair offsets
     const u32* query_ids;    // device, absolute pair offsets, or nullptr for dense rows
-    u32 n_rows;
-    u64 e_begin, e_end;
     int* out;                // 3 ints per pair, absolute pair offsets
-    unsigned long long* cursor;
+    // Work queues, one per XCD: queue x owns the batch rows qorder[qb[x] .. qb[x+1]); qcum is the
+    // running pair count over qorder.  All waves of an XCD pull from that XCD's queue, so the 32 CUs
+    // sharing one 4 MiB L2 work on the same reference (its 0.8 MB index stays L2-resident); an XCD
+    // whose queue runs dry steals from the next one.  Placement is a speed matter only.
+    const u32* qorder;
+    const u64* qcum;
+    u32 qb[NQUEUES + 1];
+    unsigned long long* cursor;   // NQUEUES tickets counters
 };
+
+__device__ __forceinline__ u32 xcc_id()
+{
+    u32 x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7u;
+}
 
 __global__ void __launch_bounds__(256) k_pairs(PairArgs a)
 {
     const int lane = threadIdx.x & 63;
     __shared__ u32 s_seed[4][SEED_SLOTS + 256];
     u32* const lds = s_seed[threadIdx.x >> 6];
+    u32 qx = xcc_id() % NQUEUES, dry = 0;
     for (;;) {
         // One ticket per wave.  NB: this is the only lane-dependent branch of the persistent loop.
         // A second `if (lane == 0)` at the loop tail (the result store) let the compiler thread the
         // two branches across the back-edge and split lane 0 from lanes 1..63, which then spun on a
         // dead lane's ticket; the store below is therefore done by every lane.
         unsigned long long t = 0;
-        if (lane == 0) t = atomicAdd(a.cursor, 1ULL);
+        if (lane == 0) t = atomicAdd(&a.cursor[qx], 1ULL);
         const u32 tlo = __builtin_amdgcn_readfirstlane((u32)t);
         const u32 thi = __builtin_amdgcn_readfirstlane((u32)(t >> 32));
-        const unsigned long long e = (((unsigned long long)thi << 32) | tlo) + a.e_begin;
-        if (e >= a.e_end) break;
-        // row of pair e: last k with row_off[k] <= e
-        u32 lo = 0, hi = a.n_rows;
+        const u32 rb = a.qb[qx], re = a.qb[qx + 1];
+        const u64 tk = a.qcum[rb] + (((u64)thi << 32) | tlo);
+        if (tk >= a.qcum[re]) {                   // this queue is dry: move on, leave after NQUEUES dry queues
+            if (++dry >= NQUEUES) break;
+            qx = (qx + 1) % NQUEUES;
+            continue;
+        }
+        u32 lo = rb, hi = re;                     // last row of the queue with qcum[row] <= tk
         while (hi - lo > 1) {
             u32 mid = (lo + hi) >> 1;
-            if (a.row_off[mid] <= e) lo = mid; else hi = mid;
+            if (a.qcum[mid] <= tk) lo = mid; else hi = mid;
         }
-        const u32 slot = lo;
+        const u32 slot = a.qorder[lo];
         const u32 r = a.ref_ids[slot];
-        u32 q;
-        if (a.query_ids) q = a.query_ids[e];
-        else { u32 j = (u32)(e - a.row_off[slot]); q = j + (j >= r ? 1u : 0u); }
+        const u32 j = (u32)(tk - a.qcum[lo]);
+        const u64 e = a.row_off[slot] + j;
+        const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
 
         const int Lr = a.G.L[r], Lq = a.G.L[q];
         const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
@@ -477,7 +494,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     int rc = ensure_slabs(c, n_rows);
     if (rc) return rc;
 
-    u32* d_ref = nullptr; u64* d_off = nullptr; u32* d_q = nullptr;
+    u32* d_ref = nullptr; u64* d_off = nullptr; u32* d_q = nullptr; u32* d_qorder = nullptr; u64* d_qcum = nullptr;
+    HIPCHK(c, hipMalloc(&d_qorder, (size_t)n_rows * 4));
+    HIPCHK(c, hipMalloc(&d_qcum, (size_t)(n_rows + 1) * 8));
     HIPCHK(c, hipMalloc(&d_ref, (size_t)n_rows * 4));
     HIPCHK(c, hipMalloc(&d_off, (size_t)(n_rows + 1) * 8));
     HIPCHK(c, hipMemcpyAsync(d_ref, ref_ids, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
@@ -506,9 +525,31 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.dirz = c->d_dirz; pa.ent = c->d_ent;
             pa.dir_stride = c->dir_stride; pa.ent_stride = c->ent_stride;
             pa.ref_ids = d_ref + k0; pa.row_off = d_off + k0; pa.query_ids = d_q;
-            pa.n_rows = rows; pa.e_begin = e0; pa.e_end = e1;
             pa.out = d_out; pa.cursor = c->d_cursor;
-            HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, sizeof(unsigned long long), c->stream));
+            // rows -> queues: longest row first onto the least loaded queue (equal rows: round robin)
+            std::vector<u32> by_size(rows);
+            for (u32 k = 0; k < rows; ++k) by_size[k] = k;
+            std::stable_sort(by_size.begin(), by_size.end(), [&](u32 x, u32 y) {
+                return row_off[k0 + x + 1] - row_off[k0 + x] > row_off[k0 + y + 1] - row_off[k0 + y]; });
+            std::vector<std::vector<u32>> queue(NQUEUES);
+            u64 load[NQUEUES] = {0};
+            for (u32 k : by_size) {
+                u32 best = 0;
+                for (u32 x = 1; x < NQUEUES; ++x) if (load[x] < load[best]) best = x;
+                queue[best].push_back(k);
+                load[best] += row_off[k0 + k + 1] - row_off[k0 + k];
+            }
+            std::vector<u32> qorder; std::vector<u64> qcum(1, 0);
+            for (u32 x = 0; x < NQUEUES; ++x) {
+                pa.qb[x] = (u32)qorder.size();
+                for (u32 k : queue[x]) { qorder.push_back(k); qcum.push_back(qcum.back() + (row_off[k0 + k + 1] - row_off[k0 + k])); }
+            }
+            pa.qb[NQUEUES] = (u32)qorder.size();
+            HIPCHK(c, hipMemcpyAsync(d_qorder, qorder.data(), qorder.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_qcum, qcum.data(), qcum.size() * 8, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));       // the host vectors die at the end of this scope
+            pa.qorder = d_qorder; pa.qcum = d_qcum;
+            HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, NQUEUES * sizeof(unsigned long long), c->stream));
             u64 waves = e1 - e0;
             u32 blocks = (u32)std::min<u64>((waves + 3) / 4, max_blocks);
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -536,7 +577,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         }
         c->tm.pairs += e1 - e0;
     }
-    hipFree(d_ref); hipFree(d_off); hipFree(d_q);
+    hipFree(d_ref); hipFree(d_off); hipFree(d_q); hipFree(d_qorder); hipFree(d_qcum);
     return LZANI_OK;
 }
 
@@ -564,7 +605,7 @@ int lzani_create(const lzani_params* p, int device_id, lzani_ctx** out)
     c->P = P;
     c->dev = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
-              hipMalloc(&c->d_cursor, sizeof(unsigned long long)) == hipSuccess;
+              hipMalloc(&c->d_cursor, NQUEUES * sizeof(unsigned long long)) == hipSuccess;
     for (int k = 0; ok && k < 4; ++k) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
     if (!ok) { lzani_destroy(c); return LZANI_ERR_DEVICE; }
     *out = c;
