@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--genomes", type=int, default=0, help="0 = 1000*sqrt(gpus)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU rehearsals)")
+    ap.add_argument("--device", type=int, default=-1, help="force the HIP device ordinal (rehearsals: all ranks on GPU 0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,11 +112,15 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    dev = local_rank if args.device < 0 else args.device
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     n = args.genomes or int(round(1000 * math.sqrt(max(world, 1))))
     names, seqs = SG.make_set(n, args.seed)
@@ -124,7 +130,7 @@ def main():
     seqs = [seqs[i] for i in order]
     lens = lens[order]
 
-    eng = L.Engine(None, device=local_rank)
+    eng = L.Engine(None, device=dev)
     params = eng.params
     eng.set_genomes(seqs)                      # untimed: genomes resident in HBM before the timed region
 
@@ -137,7 +143,10 @@ def main():
     def step():
         eng.run_rows_device(ref_ids, row_off, None, shard.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, shard)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, shard)
+            else:
+                dist.all_gather(list(gathered.view(world, -1).unbind(0)), shard)
 
     def fence():
         torch.cuda.synchronize()
@@ -203,12 +212,24 @@ def main():
             out["cpu_baseline"]["parity_on_sample"] = "bit-exact" if ok else "MISMATCH"
         else:
             out["cpu_baseline"] = None
+            if world > 1:
+                # N > 1: reassemble the gathered shards and spot-check pairs from every rank's rows
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle as O
+                res = SH.assemble(gathered.cpu().numpy(), n, world)
+                ok = True
+                for k in range(48):
+                    r = (k * 7919 + k % world) % n
+                    q = (r + 1 + (k * 104729) % (n - 1)) % n
+                    ok &= tuple(int(x) for x in res[r, q]) == O.oracle_pair(seqs[r], seqs[q], params)
+                out["parity_on_sample"] = "bit-exact" if ok else "MISMATCH"
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return 0 if (out is None or not out.get("cpu_baseline") or out["cpu_baseline"].get("parity_on_sample") != "MISMATCH") else 1
+    bad = out is not None and "MISMATCH" in (out.get("parity_on_sample"), (out.get("cpu_baseline") or {}).get("parity_on_sample"))
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":

@@ -185,14 +185,13 @@ LZ_HD void key_slot(const IndexView& I, u64 key, u32& bucket, u32& tag)
 
 // best_anchor (parser.cpp:514-531 == 585-602): over the reference positions holding the same
 // mal-mer, ascending, the longest common prefix >= mal; first (smallest position) wins ties.
-LZ_HD void best_anchor(const Params& P, const TextView& R, const TextView& Q, const IndexView& I,
-                       int qp, int& ap, int& al)
+LZ_HD void anchor_lookup(const Params& P, const TextView& R, const TextView& Q, const IndexView& I,
+                         u64 h, int qp, int& ap, int& al)     // h = mix_key(mal-mer at qp)
 {
     ap = 0; al = 0;
-    u64 key;
-    if (!kmer_at(Q, qp, P.mal, key)) return;
-    u32 b, tag;
-    key_slot(I, key, b, tag);
+    int tb = I.kb - I.dirbits;
+    u32 b = (u32)(h >> tb);
+    u32 tag = (u32)(h & lowmask(tb)) & I.tagmask;
     u32 s = I.dirz[b], e = I.dirz[b + 1];
     u32 pm = (u32)lowmask(I.posbits);
     if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); return; }
@@ -203,6 +202,15 @@ LZ_HD void best_anchor(const Params& P, const TextView& R, const TextView& Q, co
         int m = equal_len(R, p, Q, qp, 0);
         if (m >= P.mal && m > al) { al = m; ap = p; }
     }
+}
+
+LZ_HD void best_anchor(const Params& P, const TextView& R, const TextView& Q, const IndexView& I,
+                       int qp, int& ap, int& al)
+{
+    ap = 0; al = 0;
+    u64 key;
+    if (!kmer_at(Q, qp, P.mal, key)) return;
+    anchor_lookup(P, R, Q, I, mix_key(key, I.kb), qp, ap, al);
 }
 
 // Seed selection rule (parser.cpp:566-578): longer wins; on a tie the one strictly nearer to
@@ -347,6 +355,7 @@ LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool
 //                                   first step l in [0,n) whose evaluation gives len >= msl
 //   ExtMasks ext_scan(prevB, B, n)
 //   int  best_split(Lm, Rm, to_scan) argmax_s popc(Lm & low(s)) + popc(Rm >> s), last max wins
+//   void stamp(section)             profiling hook (no-op outside the LZANI_STAMPS diagnostic build)
 template <class W>
 struct PairMachine {
     W& w;
@@ -443,6 +452,7 @@ struct PairMachine {
             if (++rounds > D + 8) { LZ_GUARD_TRIP(3); out[0] = -1; out[1] = i; out[2] = lit; return; }
             int n = imin(64, iend - i);
             int lane = 0, bpos = 0, blen = 0;
+            w.stamp(1);
             if (!w.find_event(i, n, trk, r_end, lit, lane, bpos, blen)) {
                 i += n; lit += n;
                 if (lit > P.mqd) trk = false;
@@ -451,6 +461,7 @@ struct PairMachine {
             i += lane; lit += lane;
             bool strk = trk && lit <= P.mqd;
             int ref_pred = r_end + lit;
+            w.stamp(3);
             if (strk && iabs(bpos - ref_pred) <= P.mrd) {
                 // close match: fill the gap, then the match itself (parser.cpp:630-635; quirk Q2)
                 gap_fill(i - lit, r_end, bpos + blen, lit);
@@ -476,10 +487,12 @@ struct PairMachine {
             r_end = bpos + blen;
             lit = 0;
             trk = true;
+            w.stamp(5);
             int e = extend_forward(i, r_end);
             i += e; r_end += e;
             prev_re = i;
         }
+        w.stamp(6);
         if (trk)   // tail compare against r_end - msl (parser.cpp:713, quirk Q3)
             seg_range(i - lit, r_end - P.msl, lit + (D - i));
         g.finalize();

@@ -24,6 +24,9 @@
 #include "../../include/lzani.h"
 
 __device__ int g_guard_trip = 0;   // see LZ_GUARD_TRIP in lzani_core.h
+#ifdef LZANI_STAMPS
+__device__ unsigned long long g_stamp_acc[8];
+#endif
 
 #include "lzani_core.h"
 #include "lzani_layout.h"
@@ -33,9 +36,32 @@ namespace lzani {
 struct GenomeTab {
     const u64* t2;       // all packed texts, concatenated
     const u64* nm;       // all N masks, concatenated
-    const u64* nmoff;    // per genome: word offset into nm (t2 offset is twice that)
+    const u64* nmoff;    // per genome: word offset into nm (t2 offset is twice that, k-mer arrays 64x)
     const int* L;        // per genome: sequence length
+    const u32* kmL;      // per text position: mix_key(mal-mer) or KM_INVALID   (fast path: mal, msl <= 15)
+    const u32* kmS;      // per text position: msl-mer or KM_INVALID
 };
+
+enum : u32 { KM_INVALID = 0xFFFFFFFFu };
+
+// k_kmers: one thread per text position of every genome: the two k-mer words the pair kernel and
+// the index build read instead of re-extracting k-mers (the reference recomputes them per pair,
+// parser.cpp:46-47; here once per genome and run).
+__global__ void k_kmers(GenomeTab G, u32* __restrict__ kmL, u32* __restrict__ kmS, int mal, int msl, int mrd, int Tmax)
+{
+    u32 g = blockIdx.y;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int T = ref_text_len(G.L[g], mrd);
+    if (p >= Tmax || p >= T) return;
+    u64 o = G.nmoff[g];
+    TextView R{G.t2 + 2 * o, G.nm + o, T};
+    u64 key;
+    u32 a = KM_INVALID, b = KM_INVALID;
+    if (kmer_at(R, p, mal, key)) a = (u32)mix_key(key, 2 * mal);
+    if (kmer_at(R, p, msl, key)) b = (u32)key;
+    kmL[64 * o + p] = a;
+    kmS[64 * o + p] = b;
+}
 
 // ------------------------------------------------------------------------------------------
 // k_pack: one thread per 64-symbol block of a reference text.
@@ -89,13 +115,20 @@ __device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, 
     int T = ref_text_len(a.G.L[g], a.mrd);
     if (p + a.mal > T) return false;
     u64 o = a.G.nmoff[g];
-    TextView R{a.G.t2 + 2 * o, a.G.nm + o, T};
-    u64 key;
-    if (!kmer_at(R, p, a.mal, key)) return false;
-    IndexView iv;
-    iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
-    u32 tag;
-    key_slot(iv, key, bucket, tag);
+    u64 h;
+    if (a.G.kmL) {
+        u32 v = a.G.kmL[64 * o + p];
+        if (v == KM_INVALID) return false;
+        h = v;
+    } else {
+        TextView R{a.G.t2 + 2 * o, a.G.nm + o, T};
+        u64 key;
+        if (!kmer_at(R, p, a.mal, key)) return false;
+        h = mix_key(key, a.geo.kb);
+    }
+    int tb = a.geo.kb - a.geo.dirbits;
+    bucket = (u32)(h >> tb);
+    u32 tag = (u32)(h & lowmask(tb)) & a.geo.tagmask;
     entry = (tag << a.geo.posbits) | (u32)p;
     return true;
 }
@@ -173,6 +206,7 @@ __global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, 
 // ------------------------------------------------------------------------------------------
 enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS, NQUEUES = 8 };
 
+template <bool FAST>
 struct DevWave {
     const Params& P;
     TextView R, Q;
@@ -181,6 +215,23 @@ struct DevWave {
     u32* heads;      // per-wave LDS: SEED_SLOTS chain heads
     u32* nexts;      // 128 chain links
     u32* keys;       // 128 window msl-mers
+    const u32* rkS;  // FAST: msl-mers of the reference text, one per position
+    const u32* qkL;  // FAST: hashed mal-mers of the query text
+    const u32* qkS;  // FAST: msl-mers of the query text
+#ifdef LZANI_STAMPS
+    // diagnostic build only: cycles per section, summed per wave, added to g_stamp_acc at pair end
+    mutable unsigned long long t0;
+    mutable unsigned long long acc[8];
+    mutable int cur;
+    __device__ __forceinline__ void stamp(int k) const
+    {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        acc[cur] += t - t0; cur = k; t0 = t;
+    }
+#else
+    __device__ __forceinline__ void stamp(int) const {}
+#endif
 
     __device__ __forceinline__ u64 mism_fwd(int q0, int r0, int n) const
     {
@@ -206,8 +257,13 @@ struct DevWave {
         __builtin_amdgcn_wave_barrier();
         for (int pass = 0; pass < 2; ++pass) {
             int idx = lane + 64 * pass;
-            u64 rk;
-            if (idx < W && kmer_at(R, r_end + idx, P.msl, rk)) {
+            u64 rk = 0;
+            bool ok = false;
+            if (idx < W) {
+                if (FAST) { u32 v = rkS[r_end + idx]; ok = v != KM_INVALID; rk = v; }
+                else ok = kmer_at(R, r_end + idx, P.msl, rk);
+            }
+            if (ok) {
                 u32 slot = ((u32)rk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS);
                 keys[idx] = (u32)rk;
                 nexts[idx] = atomicExch(&heads[slot], (u32)idx);
@@ -215,8 +271,13 @@ struct DevWave {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        u64 qk;
-        if (lane < nt && kmer_at(Q, i + lane, P.msl, qk)) {
+        u64 qk = 0;
+        bool qok = false;
+        if (lane < nt) {
+            if (FAST) { u32 v = qkS[i + lane]; qok = v != KM_INVALID; qk = v; }
+            else qok = kmer_at(Q, i + lane, P.msl, qk);
+        }
+        if (qok) {
             const u32 lim = (u32)(lit + lane + P.mrd);          // this step's window is [0, lim)
             u64 c0 = 0, c1 = 0;
             u32 slot = ((u32)qk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS);
@@ -244,7 +305,13 @@ struct DevWave {
                                                int& ev_lane, int& bpos, int& blen) const
     {
         int bp = 0, bl = 0;
-        if (lane < n) best_anchor(P, R, Q, I, i + lane, bp, bl);
+        if (lane < n) {
+            if (FAST) {
+                u32 h = qkL[i + lane];
+                if (h != KM_INVALID) anchor_lookup(P, R, Q, I, h, i + lane, bp, bl);
+            } else best_anchor(P, R, Q, I, i + lane, bp, bl);
+        }
+        stamp(2);
         const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
         if (nt > 0) {                                                // wave-uniform
             int sp = 0, sl = 0;
@@ -258,6 +325,7 @@ struct DevWave {
             }
         }
         u64 hit = __ballot(lane < n && bl >= P.msl);
+        stamp(7);
         if (!hit) return false;
         ev_lane = ctz64(hit);
         bpos = __builtin_amdgcn_readlane(bp, ev_lane);     // ev_lane is wave-uniform (from the ballot)
@@ -312,7 +380,8 @@ __device__ __forceinline__ u32 xcc_id()
     return x & 7u;
 }
 
-__global__ void __launch_bounds__(256) k_pairs(PairArgs a)
+template <bool FAST>
+__global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 {
     const int lane = threadIdx.x & 63;
     __shared__ u32 s_seed[4][SEED_SLOTS + 256];
@@ -352,11 +421,22 @@ __global__ void __launch_bounds__(256) k_pairs(PairArgs a)
         iv.dirz = a.dirz + slot * a.dir_stride;
         iv.ent = a.ent + slot * a.ent_stride;
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
-        DevWave w{a.P, TextView{a.G.t2 + 2 * ro, a.G.nm + ro, T}, TextView{a.G.t2 + 2 * qo, a.G.nm + qo, D}, iv, lane,
-                  lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128};
-        PairMachine<DevWave> m(w, a.P, T, D);
+        DevWave<FAST> w{a.P, TextView{a.G.t2 + 2 * ro, a.G.nm + ro, T}, TextView{a.G.t2 + 2 * qo, a.G.nm + qo, D}, iv, lane,
+                        lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128,
+                        FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
+                        FAST ? a.G.kmS + 64 * qo : nullptr};
+        PairMachine<DevWave<FAST>> m(w, a.P, T, D);
         int res[3];
+#ifdef LZANI_STAMPS
+        for (int k = 0; k < 8; ++k) w.acc[k] = 0;
+        w.cur = 0;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.t0) :: "memory");
+#endif
         m.run(res);
+#ifdef LZANI_STAMPS
+        w.stamp(0);
+        if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamp_acc[k], w.acc[k]);
+#endif
         int* o = a.out + 3 * e;          // every lane stores the same wave-uniform values
         o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
     }
@@ -385,6 +465,10 @@ struct lzani_ctx {
     u64* d_nm = nullptr;
     u64* d_nmoff = nullptr;
     int* d_L = nullptr;
+    u32* d_kmL = nullptr;     // k-mer arrays (fast path: mal, msl <= 15), 64 entries per nm word
+    u32* d_kmS = nullptr;
+    u64 total_nm = 0;
+    bool kmers_ready = false;
 
     u32* d_dirz = nullptr;
     u32* d_ent = nullptr;
@@ -421,8 +505,8 @@ int fail(lzani_ctx* c, int code, const std::string& msg)
 
 void free_genomes(lzani_ctx* c)
 {
-    hipFree(c->d_t2); hipFree(c->d_nm); hipFree(c->d_nmoff); hipFree(c->d_L);
-    c->d_t2 = c->d_nm = c->d_nmoff = nullptr; c->d_L = nullptr;
+    hipFree(c->d_t2); hipFree(c->d_nm); hipFree(c->d_nmoff); hipFree(c->d_L); hipFree(c->d_kmL); hipFree(c->d_kmS);
+    c->d_t2 = c->d_nm = c->d_nmoff = nullptr; c->d_L = nullptr; c->d_kmL = c->d_kmS = nullptr; c->kmers_ready = false;
     c->n = 0;
 }
 void free_slabs(lzani_ctx* c)
@@ -447,7 +531,7 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     return LZANI_OK;
 }
 
-GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmoff, c->d_L}; }
+GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmoff, c->d_L, c->d_kmL, c->d_kmS}; }
 
 // Index build of `rows` references (device list d_ref_ids) into slots 0..rows-1.
 int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
@@ -459,6 +543,17 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
     ia.dir_stride = c->dir_stride; ia.ent_stride = c->ent_stride;
     ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo;
     const u32 nb = 1u << c->geo.dirbits;
+    if (c->d_kmL && !c->kmers_ready) {            // per-genome k-mer words, inside the timed index stage
+        for (u32 g0 = 0; g0 < c->n; g0 += 32768) {
+            u32 cnt = std::min<u32>(32768, c->n - g0);
+            GenomeTab G = gtab(c);
+            G.nmoff += g0; G.L += g0;
+            hipLaunchKernelGGL(k_kmers, dim3((c->Tmax + 255) / 256, cnt), dim3(256), 0, c->stream,
+                               G, c->d_kmL, c->d_kmS, c->P.mal, c->P.msl, c->P.mrd, c->Tmax);
+        }
+        c->kmers_ready = true;
+        c->tm.index_launches += 1;
+    }
     HIPCHK(c, hipMemsetAsync(c->d_dirz, 0, (size_t)rows * c->dir_stride * 4, c->stream));
     dim3 gp((c->Tmax + 255) / 256, rows);
     hipLaunchKernelGGL(k_idx_count, gp, dim3(256), 0, c->stream, ia, c->Tmax);
@@ -476,6 +571,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 {
     if (!c->n) return fail(c, LZANI_ERR_STATE, "lzani_run_rows: no genomes set");
     c->tm = lzani_timing{};
+    c->kmers_ready = false;                       // recomputed inside every run: it is part of the path's work
     if (n_rows == 0) return LZANI_OK;
     const u64 n_pairs = row_off[n_rows];
     for (u32 k = 0; k < n_rows; ++k) {
@@ -553,7 +649,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             u64 waves = e1 - e0;
             u32 blocks = (u32)std::min<u64>((waves + 3) / 4, max_blocks);
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-            hipLaunchKernelGGL(k_pairs, dim3(blocks), dim3(256), 0, c->stream, pa);
+            if (c->d_kmL) hipLaunchKernelGGL(k_pairs<true>, dim3(blocks), dim3(256), 0, c->stream, pa);
+            else hipLaunchKernelGGL(k_pairs<false>, dim3(blocks), dim3(256), 0, c->stream, pa);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
             c->tm.pair_launches += 1;
@@ -561,6 +658,20 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         if (trace_on()) { HIPCHK(c, hipEventSynchronize(c->ev[1])); TRACE("index built"); }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         TRACE("pairs done");
+#ifdef LZANI_STAMPS
+        {
+            unsigned long long acc[8];
+            HIPCHK(c, hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_stamp_acc), sizeof acc));
+            unsigned long long tot = 0;
+            for (int k = 0; k < 8; ++k) tot += acc[k];
+            fprintf(stderr, "[lzani stamps] pairs=%llu total_cycles/pair=%.0f shares:", (unsigned long long)(e1 - e0), (double)tot / (double)(e1 - e0));
+            const char* nm[8] = {"setup", "anchors", "seeds", "event", "-", "ext_fwd", "tail", "post_ballot"};
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)acc[k] / (double)tot);
+            fprintf(stderr, "\n");
+            unsigned long long z[8] = {0};
+            HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof z));
+        }
+#endif
         int trip = 0;
         HIPCHK(c, hipMemcpyFromSymbol(&trip, HIP_SYMBOL(g_guard_trip), sizeof(int)));
         if (trip) {
@@ -659,6 +770,11 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
     HIPCHK(c, hipMalloc(&c->d_nm, total_nm * 8));
     HIPCHK(c, hipMalloc(&c->d_nmoff, (size_t)n * 8));
     HIPCHK(c, hipMalloc(&c->d_L, (size_t)n * 4));
+    c->total_nm = total_nm;
+    if (c->P.mal <= 15 && c->P.msl <= 15) {
+        HIPCHK(c, hipMalloc(&c->d_kmL, total_nm * 64 * 4));
+        HIPCHK(c, hipMalloc(&c->d_kmS, total_nm * 64 * 4));
+    }
     // stage the codes through one pinned-size host buffer per chunk of genomes
     {
         std::vector<uint8_t> stage;

@@ -16,7 +16,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "liblzani_hip.so")
+LIB_PATH = os.environ.get("LZANI_LIB") or os.path.join(HERE, "liblzani_hip.so")   # LZANI_LIB: diagnostic builds
 SRC = os.path.join(HERE, "csrc", "lzani_hip.hip")
 
 PARAM_ORDER = ("mal", "msl", "mrd", "mqd", "reg", "aw", "am", "ar")

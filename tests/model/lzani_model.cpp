@@ -69,6 +69,7 @@ struct HostWave {
     TextView R, Q;
     IndexView I;
 
+    void stamp(int) const {}
     u64 mism_fwd(int q0, int r0, int n) const
     {
         u64 m = 0;
