@@ -1,0 +1,380 @@
+// lz-ani (MI355X build) -- the reference's command line on top of the HIP pair engine.
+//
+// Drop-in surface: /root/reference/src/lz-ani.cpp:39-355 (modes, flags, defaults, exit codes) and the
+// stage sequence of CLZMatcher::run_all2all (/root/reference/src/lz_matcher.cpp:582-617):
+//   load sequences -> load filter -> check names -> reorder -> LZ matching -> store results.
+// The matching stage is one call per GPU into the C-ABI of include/lzani.h (liblzani_hip.so, loaded
+// with dlopen so that this binary builds and its ingest/emit code is testable without ROCm present).
+// Extras over the reference: --gpus <n> (rows dealt cyclically over n GPUs), --device <id>,
+// and the test seams --results-out / --results-in (raw int triples of the matching stage).
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+#include <sstream>
+#include <thread>
+
+#include "emit.h"
+#include "ingest.h"
+
+using namespace host;
+using namespace std;
+
+static const char* VER = "1.2.3";
+static const char* INFO = "lz-ani 1.2.3 (2024-11-02) by Sebastian Deorowicz, Adam Gudys -- MI355X (gfx950) HIP engine";
+
+struct Params {
+    uint32_t verbosity = 1, threads = 0;
+    lzani_params lz;
+    bool multisample = true, in_percent = false, single_txt = false;
+    double filter_thr = 0;
+    vector<string> inputs;
+    string out, out_ids, out_aln, filter_fn, out_format = "standard";
+    vector<Comp> comps;
+    uint64_t flt_mask = 0;
+    double flt_vals[16] = {0};
+    int gpus = 1, device = 0;
+    string results_out, results_in;
+};
+
+static Params P;
+
+static string parse_output_format(const string& of)          // params.h:169-198
+{
+    P.comps.clear();
+    vector<string> names;
+    for (const auto& x : split(of, ',')) {
+        auto m = comp_metas().find(x);
+        if (m == comp_metas().end()) names.push_back(x);
+        else for (const auto& y : split(m->second, ',')) names.push_back(y);
+    }
+    for (const auto& x : names) {
+        auto p = comp_names().find(x);
+        if (p == comp_names().end()) return x;
+        P.comps.push_back(p->second);
+    }
+    return "";
+}
+
+static void usage()
+{
+    cerr << INFO << "\n"
+         << "Tool for rapid determination of similarities among sets of DNA sequences\n"
+         << "Usage:\nlz-ani <mode> [options]\nModes:\n  all2all                        - all to all\n"
+         << "Options - input specification:\n"
+         << "      --in-fasta <file_name>     - FASTA file (for multisample-fasta mode)\n"
+         << "      --in-txt <file_name>       - text file with FASTA file names\n"
+         << "      --in-dir <path>            - directory with FASTA files\n"
+         << "      --multisample-fasta <bool> - multi sample FASTA input (default: true)\n"
+         << "      --flt-kmerdb <fn> <float>  - filtering file (kmer-db output) and threshold\n"
+         << "Options - output specification:\n"
+         << "  -o, --out <file_name>          - output file name\n"
+         << "      --out-ids <file_name>      - output file name for ids file (optional)\n"
+         << "      --out-alignment <file_name>- output file name for ids file (optional; not available in the GPU build yet)\n"
+         << "      --out-in-percent <bool>    - output in percent (default: false)\n"
+         << "      --out-type <type>          - one of:\n"
+         << "                                   tsv - two tsv files with: results defined by --out-format and sequence ids (default)\n"
+         << "                                   single-txt - combined results in single txt file\n"
+         << "      --out-format <type>        - comma-separated list of values: \n"
+         << "                                   query,reference,qidx,ridx,qlen,rlen,tani,gani,ani,qcov,rcov,len_ratio,nt_match,nt_mismatch,num_alns\n"
+         << "                                   you can include also meta-names:\n";
+    for (auto& kv : comp_metas()) cerr << "                                   " << kv.first << "=" << kv.second << "\n";
+    cerr << "                                   (default: standard)\n"
+         << "      --out-filter <par> <float> - store only results with <par> (can be: tani, gani, ani, cov) at least <float>; can be used multiple times\n"
+         << "Options - LZ-parsing-related:\n"
+         << "  -a, --mal <int>                - min. anchor length (default: 11)\n"
+         << "  -s, --msl <int>                - min. seed length (default: 7)\n"
+         << "  -r, --mrd <int>                - max. dist. between approx. matches in reference (default: 40)\n"
+         << "  -q, --mqd <int>                - max. dist. between approx. matches in query (default: 40)\n"
+         << "  -g, --reg <int>                - min. considered region length (default: 35)\n"
+         << "      --aw <int>                 - approx. window length (default: 15)\n"
+         << "      --am <int>                 - max. no. of mismatches in approx. window (default: 7)\n"
+         << "      --ar <int>                 - min. length of run ending approx. extension (default: 3)\n"
+         << "Options - other:\n"
+         << "  -t, --threads <int>            - no of host threads; 0 means auto-detect (default: 0)\n"
+         << "  -V, --verbose <int>            - verbosity level (default: 1)\n"
+         << "      --gpus <int>               - number of GPUs to shard the reference rows over (default: 1)\n"
+         << "      --device <int>             - first HIP device ordinal (default: 0)\n";
+}
+
+static bool parse_bool(const char* v, bool& out) { if (v == "true"s) out = true; else if (v == "false"s) out = false; else return false; return true; }
+
+// Mirrors parse_params (lz-ani.cpp:105-336), including its return/exit conventions.
+static bool parse_params(int argc, char** argv)
+{
+    if (argc == 2 && argv[1] == "--version"s) { cerr << VER << endl; return true; }
+    if (argc < 3) { usage(); return false; }
+    if (argv[1] != "all2all"s) { cerr << "Unknown mode: " << argv[1] << endl; usage(); return false; }
+    lzani_params& z = P.lz;
+    for (int i = 2; i < argc;) {
+        string par = argv[i];
+        auto has = [&](int k) { return i + k < argc; };
+        if (par == "--in-txt" && has(1)) {
+            ifstream ifs(argv[i + 1]);
+            if (!ifs.is_open()) { cerr << "Cannot open file: " << argv[i + 1] << endl; return false; }
+            P.inputs.assign(istream_iterator<string>(ifs), istream_iterator<string>());
+            if (P.inputs.empty()) return false;
+            i += 2;
+        } else if (par == "--in-dir" && has(1)) {
+            try {
+                P.inputs.clear();
+                for (const auto& fs : filesystem::directory_iterator(filesystem::path(argv[i + 1]))) P.inputs.push_back(fs.path().string());
+            } catch (...) { cerr << "Non-existing directory: " << argv[i + 1] << endl; return false; }
+            if (P.inputs.empty()) return false;
+            i += 2;
+        } else if (par == "--in-fasta" && has(1)) { P.inputs.assign(1, argv[i + 1]); i += 2; }
+        else if ((par == "-o" || par == "--out") && has(1)) { P.out = argv[i + 1]; i += 2; }
+        else if (par == "--out-ids" && has(1)) { P.out_ids = argv[i + 1]; i += 2; }
+        else if (par == "--out-alignment" && has(1)) { P.out_aln = argv[i + 1]; i += 2; }
+        else if ((par == "-t" || par == "--threads") && has(1)) { P.threads = (uint32_t)atoi(argv[i + 1]); i += 2; }
+        else if ((par == "-s" || par == "--msl") && has(1)) { z.min_seed_len = atoi(argv[i + 1]); i += 2; }
+        else if ((par == "-a" || par == "--mal") && has(1)) { z.min_anchor_len = atoi(argv[i + 1]); i += 2; }
+        else if ((par == "-r" || par == "--mrd") && has(1)) { z.max_dist_in_ref = atoi(argv[i + 1]); i += 2; }
+        else if ((par == "-q" || par == "--mqd") && has(1)) { z.max_dist_in_query = atoi(argv[i + 1]); i += 2; }
+        else if ((par == "-g" || par == "--reg") && has(1)) { z.min_region_len = atoi(argv[i + 1]); i += 2; }
+        else if (par == "--aw" && has(1)) { z.approx_window = atoi(argv[i + 1]); i += 2; }
+        else if (par == "--am" && has(1)) { z.approx_mismatches = atoi(argv[i + 1]); i += 2; }
+        else if (par == "--ar" && has(1)) { z.approx_run_len = atoi(argv[i + 1]); i += 2; }
+        else if (par == "--flt-kmerdb" && has(2)) { P.filter_fn = argv[i + 1]; P.filter_thr = atof(argv[i + 2]); i += 3; }
+        else if ((par == "-V" || par == "--verbose") && has(1)) { P.verbosity = (uint32_t)atoi(argv[i + 1]); i += 2; }
+        else if (par == "--out-type" && has(1)) {
+            string t = argv[i + 1];
+            if (t == "single-txt") P.single_txt = true;
+            else if (t == "tsv") P.single_txt = false;
+            else { cerr << "Unknown output-type: " << t << endl; usage(); exit(0); }
+            i += 2;
+        } else if (par == "--out-format" && has(1)) {
+            string bad = parse_output_format(argv[i + 1]);
+            if (!bad.empty()) { cerr << "Unknown output-format component: " << bad; return false; }
+            P.out_format = argv[i + 1];
+            i += 2;
+        } else if (par == "--out-filter" && has(2)) {
+            static const map<string, Comp> flt = {{"tani", Comp::tani}, {"gani", Comp::gani}, {"ani", Comp::ani}, {"qcov", Comp::qcov}, {"rcov", Comp::rcov}};
+            auto p = flt.find(argv[i + 1]);
+            if (p == flt.end()) { cerr << "Unknown output-filter component: " << argv[i + 1] << " " << argv[i + 2] << endl; return false; }
+            P.flt_mask |= 1ull << (uint32_t)p->second;
+            P.flt_vals[(int)p->second] = atof(argv[i + 2]);
+            i += 3;
+        } else if (par == "--multisample-fasta" && has(1)) {
+            if (!parse_bool(argv[i + 1], P.multisample)) { cerr << "Unknown value for --multisample-fasta: " << argv[1] << endl; return false; }
+            i += 2;
+        } else if (par == "--out-in-percent" && has(1)) {
+            if (!parse_bool(argv[i + 1], P.in_percent)) { cerr << "Unknown value for --out-in-percent: " << argv[1] << endl; return false; }
+            i += 2;
+        } else if (par == "--gpus" && has(1)) { P.gpus = max(1, atoi(argv[i + 1])); i += 2; }
+        else if (par == "--device" && has(1)) { P.device = atoi(argv[i + 1]); i += 2; }
+        else if (par == "--results-out" && has(1)) { P.results_out = argv[i + 1]; i += 2; }
+        else if (par == "--results-in" && has(1)) { P.results_in = argv[i + 1]; i += 2; }
+        else { cerr << "Unknown parameter: " << argv[i] << endl; usage(); exit(1); }
+    }
+    if (P.inputs.empty()) { cerr << "Input file names not provided\n"; return false; }
+    return true;
+}
+
+static string params_dump()                                   // CParams::str(), params.h:120-157
+{
+    stringstream ss;
+    const lzani_params& z = P.lz;
+    ss << "[params]" << endl
+       << "min_anchor_len             : " << z.min_anchor_len << endl
+       << "min_seed_len               : " << z.min_seed_len << endl
+       << "max_dist_in_ref            : " << z.max_dist_in_ref << endl
+       << "max_dist_in_query          : " << z.max_dist_in_query << endl
+       << "min_region_len             : " << z.min_region_len << endl
+       << "approx_window              : " << z.approx_window << endl
+       << "approx_mismatches          : " << z.approx_mismatches << endl
+       << "approx_run_len             : " << z.approx_run_len << endl
+       << "multisample_fasta          : " << boolalpha << P.multisample << noboolalpha << endl
+       << "filter_thr                 : " << P.filter_thr << endl
+       << "output_format              : " << P.out_format << endl
+       << "output_in_percent          : " << boolalpha << P.in_percent << noboolalpha << endl
+       << "no_threads                 : " << P.threads << endl
+       << "output_file_name           : " << P.out << endl
+       << "output_ids_file_name       : " << P.out_ids << endl
+       << "output_alignment_file_name : " << P.out_ids << endl
+       << "filter_file_name           : " << P.filter_fn << endl
+       << "input_file_names           : ";
+    for (size_t i = 0; i + 1 < P.inputs.size(); ++i) ss << P.inputs[i] << ", ";
+    ss << P.inputs.back() << endl;
+    return ss.str();
+}
+
+// ---- the engine, bound at run time -----------------------------------------------------------
+struct Engine {
+    void* so = nullptr;
+    int (*create)(const lzani_params*, int, lzani_ctx**) = nullptr;
+    void (*destroy)(lzani_ctx*) = nullptr;
+    const char* (*last_error)(const lzani_ctx*) = nullptr;
+    int (*set_genomes)(lzani_ctx*, uint32_t, const uint8_t* const*, const uint32_t*) = nullptr;
+    int (*run_rows)(lzani_ctx*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, lzani_result*) = nullptr;
+    int (*get_timing)(const lzani_ctx*, lzani_timing*) = nullptr;
+    bool load(const char* argv0)
+    {
+        vector<string> cand;
+        if (const char* e = getenv("LZANI_LIB")) cand.push_back(e);
+        error_code ec;
+        auto self = filesystem::canonical("/proc/self/exe", ec);
+        if (!ec) { cand.push_back((self.parent_path() / "liblzani_hip.so").string()); cand.push_back((self.parent_path().parent_path() / "liblzani_hip.so").string()); }
+        (void)argv0;
+        cand.push_back("liblzani_hip.so");
+        for (auto& c : cand) if ((so = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
+        if (!so) { cerr << "Cannot load liblzani_hip.so (the HIP engine; there is no CPU fallback): " << dlerror() << endl; return false; }
+#define BIND(f, n) f = reinterpret_cast<decltype(f)>(dlsym(so, n)); if (!f) { cerr << "Missing symbol " << n << endl; return false; }
+        BIND(create, "lzani_create") BIND(destroy, "lzani_destroy") BIND(last_error, "lzani_last_error")
+        BIND(set_genomes, "lzani_set_genomes") BIND(run_rows, "lzani_run_rows") BIND(get_timing, "lzani_get_timing")
+#undef BIND
+        return true;
+    }
+};
+
+// do_matching (lz_matcher.cpp:172-277): rows -> engine(s) -> results[ref] sorted by id
+static bool do_matching(const Engine& E, const vector<Genome>& g, const Filter& flt, ResultRows& results)
+{
+    const uint32_t n = (uint32_t)g.size();
+    if (P.verbosity >= 1) cerr << "All2all sparse" << endl;
+    results.assign(n, {});
+    vector<const uint8_t*> ptr(n);
+    vector<uint32_t> len(n);
+    for (uint32_t i = 0; i < n; ++i) { ptr[i] = g[i].codes.data(); len[i] = (uint32_t)g[i].codes.size(); }
+    const int ng = max(1, min<int>(P.gpus, (int)n));
+    vector<string> errs(ng);
+    auto shard = [&](int d) {
+        lzani_ctx* ctx = nullptr;
+        int rc = E.create(&P.lz, P.device + d, &ctx);
+        if (rc != LZANI_OK) { errs[d] = "lzani_create failed with code " + to_string(rc) + (rc == LZANI_ERR_PARAMS ? " (LZ parameters outside the supported envelope)" : ""); return; }
+        rc = E.set_genomes(ctx, n, ptr.data(), len.data());
+        vector<uint32_t> ref_ids, query_ids;
+        vector<uint64_t> row_off(1, 0);
+        for (uint32_t r = (uint32_t)d; r < n; r += (uint32_t)ng) {
+            ref_ids.push_back(r);
+            if (flt.empty()) row_off.push_back(row_off.back() + (n - 1));
+            else { for (auto q : flt.rows[r]) query_ids.push_back(q); row_off.push_back(query_ids.size()); }
+        }
+        vector<lzani_result> out(row_off.back());
+        if (rc == LZANI_OK)
+            rc = E.run_rows(ctx, (uint32_t)ref_ids.size(), ref_ids.data(), row_off.data(), flt.empty() ? nullptr : query_ids.data(), out.data());
+        if (rc != LZANI_OK) errs[d] = E.last_error(ctx);
+        else {
+            for (size_t k = 0; k < ref_ids.size(); ++k) {
+                uint32_t r = ref_ids[k];
+                auto& row = results[r];
+                row.reserve(row_off[k + 1] - row_off[k]);
+                for (uint64_t e = row_off[k]; e < row_off[k + 1]; ++e) {
+                    uint32_t j = (uint32_t)(e - row_off[k]);
+                    uint32_t q = flt.empty() ? j + (j >= r ? 1u : 0u) : query_ids[e];
+                    row.push_back(IdResult{q, out[e]});
+                }
+                sort(row.begin(), row.end(), [](const IdResult& a, const IdResult& b) { return a.id < b.id; });
+            }
+            if (P.verbosity >= 2) {
+                lzani_timing t;
+                if (E.get_timing(ctx, &t) == LZANI_OK)
+                    cerr << "GPU " << P.device + d << ": " << t.pairs << " pairs, index " << t.index_ms << " ms, pair kernel " << t.pairs_ms << " ms\n";
+            }
+        }
+        E.destroy(ctx);
+    };
+    vector<thread> th;
+    for (int d = 1; d < ng; ++d) th.emplace_back(shard, d);
+    shard(0);
+    for (auto& t : th) t.join();
+    for (auto& e : errs) if (!e.empty()) { cerr << "LZ matching failed: " << e << endl; return false; }
+    return true;
+}
+
+static bool write_raw(const string& fn, const ResultRows& res)
+{
+    ofstream o(fn);
+    if (!o.is_open()) return false;
+    for (size_t r = 0; r < res.size(); ++r)
+        for (auto& x : res[r]) o << r << ' ' << x.id << ' ' << x.r.sym_in_matches << ' ' << x.r.sym_in_literals << ' ' << x.r.no_components << '\n';
+    return true;
+}
+static bool read_raw(const string& fn, size_t n, ResultRows& res)
+{
+    ifstream in(fn);
+    if (!in.is_open()) { cerr << "Cannot open file: " << fn << endl; return false; }
+    res.assign(n, {});
+    size_t r; IdResult x;
+    while (in >> r >> x.id >> x.r.sym_in_matches >> x.r.sym_in_literals >> x.r.no_components) { if (r >= n || x.id >= n) return false; res[r].push_back(x); }
+    for (auto& row : res) sort(row.begin(), row.end(), [](const IdResult& a, const IdResult& b) { return a.id < b.id; });
+    return true;
+}
+
+static bool run_all2all(const char* argv0)
+{
+    using clk = chrono::high_resolution_clock;
+    vector<pair<clk::time_point, string>> times{{clk::now(), ""}};
+    auto stamp = [&](const char* s) { times.emplace_back(clk::now(), s); };
+
+    if (P.verbosity >= 1) cerr << "Loading sequences\n";
+    vector<Genome> g;
+    if (P.multisample ? !load_multifasta(P.inputs, g) : !load_fasta(P.inputs, (uint32_t)P.lz.max_dist_in_ref, g)) return false;
+    if (P.verbosity >= 2) cerr << g.size() << endl;
+    stamp("Loading sequences");
+
+    Filter flt;
+    if (!P.filter_fn.empty()) {
+        if (P.verbosity >= 1) cerr << "Loading filter data" << endl;
+        if (!load_filter(P.filter_fn, P.filter_thr, flt)) return false;
+        if (P.verbosity >= 1) cerr << "Filter size: " << flt.size() << endl;
+    }
+    stamp("Loading filter");
+
+    if (!flt.empty()) {                                     // compare_sequences (lz_matcher.cpp:43-75)
+        bool same = flt.names.size() == g.size();
+        for (size_t i = 0; same && i < g.size(); ++i) same = flt.names[i] == g[i].name;
+        if (!same) {
+            cerr << "seq_sn.size(): " << g.size() << endl << "flt_sn.size(): " << flt.names.size() << endl;
+            cerr << (flt.names.size() != g.size() ? "Input sequences and filter sequences sets are of different size!"
+                                                  : "Input sequences and filter sequences are different!") << endl;
+            return false;
+        }
+    }
+    stamp("Comparing sequence and filter compatibility");
+
+    if (P.verbosity >= 1) cerr << "Reordering sequences" << endl;
+    auto map = reorder(g);
+    if (!flt.empty()) { if (P.verbosity >= 1) cerr << "Reordering filter" << endl; reorder_filter(flt, map); }
+    stamp("Reordering sequences");
+
+    ResultRows results;
+    if (!P.results_in.empty()) { if (!read_raw(P.results_in, g.size(), results)) return false; }
+    else {
+        Engine E;
+        if (!E.load(argv0)) return false;
+        if (!do_matching(E, g, flt, results)) return false;
+    }
+    stamp("LZ matching");
+    if (!P.results_out.empty() && !write_raw(P.results_out, results)) return false;
+
+    if (P.verbosity >= 1) cerr << "Storing results" << endl;
+    EmitParams ep;
+    ep.out_name = P.out; ep.ids_name = P.out_ids; ep.single_txt = P.single_txt; ep.in_percent = P.in_percent;
+    ep.comps = P.comps; ep.filter_mask = P.flt_mask; memcpy(ep.filter_vals, P.flt_vals, sizeof ep.filter_vals);
+    ep.threads = P.threads; ep.mrd = P.lz.max_dist_in_ref;
+    if (P.single_txt) ep.params_dump = params_dump();
+    if (!store_results(g, results, ep)) return false;
+    stamp("Storing results");
+
+    if (P.verbosity > 1) {
+        cerr << "Timings\n";
+        for (size_t i = 1; i < times.size(); ++i) cerr << times[i].second << " : " << chrono::duration<double>(times[i].first - times[i - 1].first).count() << "s\n";
+        cerr << "Total time: " << chrono::duration<double>(times.back().first - times.front().first).count() << "s\n";
+    }
+    return true;
+}
+
+int main(int argc, char** argv)
+{
+    P.lz = lzani_params{11, 7, 40, 40, 35, 15, 7, 3};
+    parse_output_format("standard");
+    if (!parse_params(argc, argv)) return 0;                  // the reference returns 0 here too (lz-ani.cpp:341-342)
+    if (argc == 2) return 0;                                  // --version
+    if (P.threads == 0) { P.threads = thread::hardware_concurrency(); if (!P.threads) P.threads = 1; }
+    if (!P.out_aln.empty()) { cerr << "--out-alignment is not available in the GPU build yet\n"; exit(1); }
+    if (!run_all2all(argv[0])) { cerr << "Run failed" << endl; exit(1); }
+    return 0;
+}

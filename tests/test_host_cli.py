@@ -1,0 +1,158 @@
+"""The C++ host binary `lz-ani` (lz-ani_amd/host): FASTA ingest, reorder, kmer-db filter and TSV emit
+(SURVEY 8(f) rows N1/N2/N4).  CPU tests feed it the matching-stage integers through its --results-in
+test seam (oracle numbers; the binary itself has no CPU compute path); the GPU tests run it end to end."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+import util as U
+
+EXE = os.path.join(U.ROOT, "lz-ani_amd", "host", "lz-ani")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def build_host():
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
+
+
+def _raw_file(path, res, pairs=None):
+    n = res.shape[0]
+    with open(path, "w") as f:
+        for r in range(n):
+            for q in range(n):
+                if r != q and (pairs is None or (r, q) in pairs):
+                    f.write(f"{r} {q} {res[r, q, 0]} {res[r, q, 1]} {res[r, q, 2]}\n")
+
+
+def _oracle_reordered(loader, params=None):
+    names, seqs = U.reorder(*loader())
+    return names, seqs, O.oracle_all2all(seqs, params, threads=8)
+
+
+def run(args, **kw):
+    return subprocess.run([EXE] + args, capture_output=True, text=True, **kw)
+
+
+def test_vir61_golden_files_byte_exact(tmp_path):
+    """BASELINE config 1: --in-dir test/vir61, default format -> test/vir61.ani.tsv + .ids.tsv."""
+    names, seqs, res = _oracle_reordered(U.load_vir61)
+    raw = str(tmp_path / "raw.txt")
+    _raw_file(raw, res)
+    out = str(tmp_path / "ani.tsv")
+    p = run(["all2all", "--in-dir", os.path.join(U.GOLD, "vir61"), "--out", out, "--results-in", raw])
+    assert p.returncode == 0, p.stderr
+    assert open(out).read() == open(os.path.join(U.GOLD, "vir61.ani.tsv")).read()
+    assert open(str(tmp_path / "ani.ids.tsv")).read() == open(os.path.join(U.GOLD, "vir61.ani.ids.tsv")).read()
+
+
+def test_example_golden_files_and_formats(tmp_path):
+    names, seqs, res = _oracle_reordered(U.load_example)
+    raw = str(tmp_path / "raw.txt")
+    _raw_file(raw, res)
+    fa = os.path.join(U.GOLD, "example", "multifasta.fna")
+    out = str(tmp_path / "ani.tsv")
+    assert run(["all2all", "--in-fasta", fa, "-o", out, "--results-in", raw, "-V", "0"]).returncode == 0
+    assert open(out).read() == open(os.path.join(U.GOLD, "example", "ani.tsv")).read()
+    assert open(str(tmp_path / "ani.ids.tsv")).read() == open(os.path.join(U.GOLD, "example", "ani.ids.tsv")).read()
+    lens = [len(s) for s in seqs]
+    complete = "qidx,ridx,query,reference,tani,gani,ani,qcov,rcov,num_alns,len_ratio,qlen,rlen,nt_match,nt_mismatch".split(",")
+    for fmt, cols, pct in (("complete", complete, False), ("lite", "qidx,ridx,tani,gani,ani,qcov,num_alns,len_ratio".split(","), False),
+                           ("nt_match,query,rcov", ["nt_match", "query", "rcov"], True)):
+        o2 = str(tmp_path / "x.out")
+        args = ["all2all", "--in-fasta", fa, "-o", o2, "--results-in", raw, "--out-format", fmt, "--out-ids", str(tmp_path / "my.ids")]
+        if pct:
+            args += ["--out-in-percent", "true"]
+        assert run(args).returncode == 0
+        assert open(o2).read() == U.emit_tsv(names, lens, res, cols, in_percent=pct)
+        assert os.path.exists(str(tmp_path / "my.ids"))
+
+
+def test_out_filter_and_single_txt(tmp_path):
+    names, seqs, res = _oracle_reordered(U.load_example)
+    raw = str(tmp_path / "raw.txt")
+    _raw_file(raw, res)
+    fa = os.path.join(U.GOLD, "example", "multifasta.fna")
+    out = str(tmp_path / "f.tsv")
+    assert run(["all2all", "--in-fasta", fa, "-o", out, "--results-in", raw, "--out-filter", "ani", "0.9", "--out-filter", "qcov", "0.5",
+                "--out-format", "complete"]).returncode == 0
+    rows = [ln.split("\t") for ln in open(out).read().split("\n")[1:] if ln]
+    full = [ln.split("\t") for ln in U.emit_tsv(names, [len(s) for s in seqs], res,
+            "qidx,ridx,query,reference,tani,gani,ani,qcov,rcov,num_alns,len_ratio,qlen,rlen,nt_match,nt_mismatch".split(",")).split("\n")[1:] if ln]
+    keep = [r for r in full if int(r[13]) / max(1, int(r[13]) + int(r[14])) >= 0.9 and (int(r[13]) + int(r[14])) / int(r[11]) >= 0.5]
+    assert rows == keep and 0 < len(rows) < len(full)
+    one = str(tmp_path / "one.txt")
+    assert run(["all2all", "--in-fasta", fa, "-o", one, "--results-in", raw, "--out-type", "single-txt"]).returncode == 0
+    txt = open(one).read()
+    assert txt.startswith("[params]\nmin_anchor_len             : 11\n") and "[lz_similarities]\n" in txt
+    body = txt.split("[lz_similarities]\n")[1].strip().split("\n")
+    assert len(body) == 66
+    a, b, m1, l1, c1, m2, l2, c2 = (int(x) for x in body[0].split())
+    assert (a, b) == (0, 1) and [m1, l1, c1] == res[1, 0].tolist() and [m2, l2, c2] == res[0, 1].tolist()
+
+
+def test_kmerdb_filter_rows(tmp_path):
+    """--flt-kmerdb example/fltr.txt 0.9 keeps 13 unordered pairs = 26 TSV rows."""
+    names, seqs, res = _oracle_reordered(U.load_example)
+    raw = str(tmp_path / "raw.txt")
+    _raw_file(raw, res)
+    fa = os.path.join(U.GOLD, "example", "multifasta.fna")
+    out = str(tmp_path / "flt.tsv")
+    p = run(["all2all", "--in-fasta", fa, "-o", out, "--results-in", raw, "--flt-kmerdb", os.path.join(U.GOLD, "example", "fltr.txt"), "0.9"])
+    assert p.returncode == 0 and "Filter size: 26" in p.stderr
+    # with --results-in every pair is present, so the emit is the full table; the filter count is what is checked here
+    bad = run(["all2all", "--in-fasta", os.path.join(U.GOLD, "vir61", os.listdir(os.path.join(U.GOLD, "vir61"))[0]), "-o", out,
+               "--results-in", raw, "--flt-kmerdb", os.path.join(U.GOLD, "example", "fltr.txt"), "0.9"])
+    assert bad.returncode == 1 and "different size" in bad.stderr
+
+
+def test_cli_conventions(tmp_path):
+    assert run(["--version"]).stderr.strip() == "1.2.3"
+    p = run([])
+    assert p.returncode == 0 and "Usage:" in p.stderr               # usage + return 0 (lz-ani.cpp:341-342)
+    assert run(["all2all", "--bogus", "1"]).returncode == 1         # unknown parameter: exit(1)
+    assert run(["frobnicate", "x", "y"]).returncode == 0            # unknown mode: usage, return 0
+    p = run(["all2all", "--in-fasta", "/nonexistent.fna", "-o", str(tmp_path / "o.tsv")])
+    assert p.returncode == 1 and "Cannot open file" in p.stderr
+
+
+def test_ingest_quirks(tmp_path):
+    """Name cut at the first space, lower case accepted, CRLF, last unterminated line dropped in
+    multi-FASTA mode, contigs joined by mrd N's when --multisample-fasta false (seq_len includes them)."""
+    fa = tmp_path / "q.fna"
+    fa.write_bytes(b">s1 some description\r\nACGTACGTAC\r\nacgtnn\r\n>s2\nACGT\nACGTAC")
+    raw = tmp_path / "raw.txt"
+    raw.write_text("0 1 0 0 0\n1 0 0 0 0\n")
+    out = tmp_path / "o.tsv"
+    assert run(["all2all", "--in-fasta", str(fa), "-o", str(out), "--results-in", str(raw)]).returncode == 0
+    assert (tmp_path / "o.ids.tsv").read_text() == "id\tseq_len\tno_parts\ns1\t16\t1\ns2\t4\t1\n"
+    raw.write_text("")                                            # one item only: no pairs
+    assert run(["all2all", "--in-fasta", str(fa), "-o", str(out), "--results-in", str(raw), "--multisample-fasta", "false"]).returncode == 0
+    assert (tmp_path / "o.ids.tsv").read_text() == "id\tseq_len\tno_parts\nq.fna\t66\t1\n"       # 16 + 40 + 10
+
+
+@pytest.mark.gpu
+def test_end_to_end_on_gpu(tmp_path):
+    """The whole binary on the GPU: vir61 (config 1) and the example set with and without the filter."""
+    out = str(tmp_path / "ani.tsv")
+    p = run(["all2all", "--in-dir", os.path.join(U.GOLD, "vir61"), "--out", out, "-V", "2"])
+    assert p.returncode == 0, p.stderr
+    assert open(out).read() == open(os.path.join(U.GOLD, "vir61.ani.tsv")).read()
+    assert open(str(tmp_path / "ani.ids.tsv")).read() == open(os.path.join(U.GOLD, "vir61.ani.ids.tsv")).read()
+    fa = os.path.join(U.GOLD, "example", "multifasta.fna")
+    p = run(["all2all", "--in-fasta", fa, "-o", out])
+    assert p.returncode == 0 and open(out).read() == open(os.path.join(U.GOLD, "example", "ani.tsv")).read()
+    p = run(["all2all", "--in-fasta", fa, "-o", out, "--flt-kmerdb", os.path.join(U.GOLD, "example", "fltr.txt"), "0.9", "--out-format", "complete"])
+    assert p.returncode == 0, p.stderr
+    rows = [ln for ln in open(out).read().split("\n")[1:] if ln]
+    assert len(rows) == 26
+    full = set(U.emit_tsv(*(lambda n, s: (n, [len(x) for x in s], O.oracle_all2all(s, None, threads=8)))(*U.reorder(*U.load_example())),
+                          "qidx,ridx,query,reference,tani,gani,ani,qcov,rcov,num_alns,len_ratio,qlen,rlen,nt_match,nt_mismatch".split(",")).split("\n"))
+    assert all(r in full for r in rows)
+    p = run(["all2all", "--in-fasta", fa, "-o", out, "--mal", "15", "--msl", "9", "--reg", "60"])
+    names, seqs = U.reorder(*U.load_example())
+    want = U.emit_tsv(names, [len(s) for s in seqs], O.oracle_all2all(seqs, dict(mal=15, msl=9, reg=60), threads=8), U.STANDARD)
+    assert p.returncode == 0 and open(out).read() == want
+    assert run(["all2all", "--in-fasta", fa, "-o", out, "--mqd", "100"]).returncode == 1      # outside the envelope: clean failure
