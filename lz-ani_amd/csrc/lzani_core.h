@@ -53,7 +53,23 @@ struct TextView {         // one packed text: `len` symbols are addressable
     const u64* t2;        // 2 bits per symbol, symbol j at bits 2*(j&31) of word j>>5
     const u64* nm;        // 1 bit per symbol, 1 = N / padding
     int len;
+    // Structure of a text whose genome holds no N: the only N symbols are the pads, so the valid
+    // symbols are [0, L) and, in a reference text, [rc0, rc0 + L); rc0 < 0 in a query view.
+    // With nfree set on both sides the N mask is never loaded (bounds do its job).
+    int L, rc0;
+    bool nfree;
 };
+
+LZ_HD TextView ref_view(const u64* t2, const u64* nm, int L, int mrd, bool nfree)
+{ return TextView{t2, nm, 2 * L + 3 * mrd, L, L + 2 * mrd, nfree}; }
+LZ_HD TextView qry_view(const u64* t2, const u64* nm, int L, int mrd, bool nfree)
+{ return TextView{t2, nm, L + mrd, L, -1, nfree}; }
+
+// N-free texts: is p a real symbol / where does the run of real symbols containing p end
+LZ_HD bool pos_valid(const TextView& t, int p)
+{ return p >= 0 && (p < t.L || (t.rc0 >= 0 && p >= t.rc0 && p < t.rc0 + t.L)); }
+LZ_HD int run_end(const TextView& t, int p)
+{ return p < t.L ? t.L : ((t.rc0 >= 0 && p >= t.rc0 && p < t.rc0 + t.L) ? t.rc0 + t.L : p); }
 
 struct IndexView {        // anchor index of one reference (all mal-mers of R)
     const u32* dirz;      // dirz[b] .. dirz[b+1] = entry range of bucket b
@@ -118,6 +134,8 @@ LZ_HD int isN_at(const TextView& t, int p) { return (int)((t.nm[p >> 6] >> (p & 
 // anything (reference: code_N_ref = 4 vs code_N_seq = 5, defs.h:28-30).
 LZ_HD int sym_match(const TextView& R, int rp, const TextView& Q, int qp)
 {
+    if (R.nfree && Q.nfree)
+        return pos_valid(R, rp) && pos_valid(Q, qp) && sym_at(R, rp) == sym_at(Q, qp);
     if (rp < 0 || rp >= R.len || qp < 0 || qp >= Q.len) return 0;
     if (isN_at(R, rp) | isN_at(Q, qp)) return 0;
     return sym_at(R, rp) == sym_at(Q, qp);
@@ -127,6 +145,19 @@ LZ_HD int sym_match(const TextView& R, int rp, const TextView& Q, int qp)
 // both ends; returns `start` even if the bound is smaller (quirk Q11).
 LZ_HD int equal_len(const TextView& R, int rp, const TextView& Q, int qp, int start)
 {
+    if (R.nfree && Q.nfree) {
+        // the first N after rp / qp is the end of the run of real symbols: fold it into the bound
+        int bound = imin(run_end(R, rp) - rp, run_end(Q, qp) - qp);
+        int n = start;
+        while (n < bound) {
+            u64 x = win2(R.t2, rp + n) ^ win2(Q.t2, qp + n);
+            u64 d = (x | (x >> 1)) & 0x5555555555555555ULL;
+            if (d) { n += ctz64(d) >> 1; break; }
+            n += 32;
+        }
+        n = imin(n, bound);
+        return n > start ? n : start;
+    }
     int bound = imin(R.len - rp, Q.len - qp);
     int n = start;
     int guard = 0;
@@ -331,20 +362,12 @@ struct ExtMasks { u64 brk, qual; };
 
 LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool& brk, bool& qual)
 {
-    // 128-bit stream: prevB is symbols -64..-1, B is symbols 0..63; window (j-aw, j]
-    brk = false; qual = false;
-    if (j >= n) return;
-    int lo = j - aw + 1;                       // may be negative (reaches into prevB)
-    int cnt;
-    if (lo >= 0) cnt = popc64((B >> lo) & lowmask(aw));
-    else cnt = popc64(B & lowmask(j + 1)) + popc64(prevB >> (64 + lo));
-    brk = cnt > am;
+    // W = the 64 stream symbols ending at symbol j (bit 63 = symbol j): funnel of prevB:B
+    u64 W = (B << (63 - j)) | ((prevB >> 1) >> j);
     int a = ar < 1 ? 1 : ar;
-    int lo2 = j - a + 1;
-    u64 bad;
-    if (lo2 >= 0) bad = (B >> lo2) & lowmask(a);
-    else bad = (B & lowmask(j + 1)) | (prevB >> (64 + lo2));
-    qual = bad == 0;
+    bool in = j < n;
+    brk = in && popc64(W >> (64 - aw)) > am;          // mismatches among the last aw symbols
+    qual = in && (W >> (64 - a)) == 0;                // the last max(ar,1) symbols all match
 }
 
 // ---- the pair state machine ------------------------------------------------------------

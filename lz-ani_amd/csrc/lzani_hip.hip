@@ -40,6 +40,7 @@ struct GenomeTab {
     const int* L;        // per genome: sequence length
     const u32* kmL;      // per text position: mix_key(mal-mer) or KM_INVALID   (fast path: mal, msl <= 15)
     const u32* kmS;      // per text position: msl-mer or KM_INVALID
+    const int* hasN;     // per genome: 1 if the sequence holds a non-ACGT symbol
 };
 
 enum : u32 { KM_INVALID = 0xFFFFFFFFu };
@@ -54,7 +55,7 @@ __global__ void k_kmers(GenomeTab G, u32* __restrict__ kmL, u32* __restrict__ km
     int T = ref_text_len(G.L[g], mrd);
     if (p >= Tmax || p >= T) return;
     u64 o = G.nmoff[g];
-    TextView R{G.t2 + 2 * o, G.nm + o, T};
+    TextView R = ref_view(G.t2 + 2 * o, G.nm + o, G.L[g], mrd, false);
     u64 key;
     u32 a = KM_INVALID, b = KM_INVALID;
     if (kmer_at(R, p, mal, key)) a = (u32)mix_key(key, 2 * mal);
@@ -68,7 +69,7 @@ __global__ void k_kmers(GenomeTab G, u32* __restrict__ kmL, u32* __restrict__ km
 // ------------------------------------------------------------------------------------------
 __global__ void k_pack(const uint8_t* __restrict__ codes, const u64* __restrict__ codeoff,
                        u64* __restrict__ t2, u64* __restrict__ nm, const u64* __restrict__ nmoff,
-                       const int* __restrict__ Ls, int mrd, u32 n)
+                       const int* __restrict__ Ls, int* __restrict__ hasN, int mrd, u32 n)
 {
     u32 g = blockIdx.y;
     if (g >= n) return;
@@ -83,7 +84,7 @@ __global__ void k_pack(const uint8_t* __restrict__ codes, const u64* __restrict_
     for (int j = 0; j < 64; ++j) {
         long p = (long)blk * 64 + j;
         int s = 4;
-        if (p < L) { int v = c[p]; s = v < 4 ? v : 4; }
+        if (p < L) { int v = c[p]; s = v < 4 ? v : 4; if (v >= 4) hasN[g] = 1; }
         else if (p >= rc0 && p < rc0 + L) { int v = c[L - 1 - (p - rc0)]; s = v < 4 ? 3 - v : 4; }
         if (s < 4) {
             if (j < 32) w0 |= (u64)s << (2 * j);
@@ -121,7 +122,7 @@ __device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, 
         if (v == KM_INVALID) return false;
         h = v;
     } else {
-        TextView R{a.G.t2 + 2 * o, a.G.nm + o, T};
+        TextView R = ref_view(a.G.t2 + 2 * o, a.G.nm + o, a.G.L[g], a.mrd, false);
         u64 key;
         if (!kmer_at(R, p, a.mal, key)) return false;
         h = mix_key(key, a.geo.kb);
@@ -421,7 +422,9 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         iv.dirz = a.dirz + slot * a.dir_stride;
         iv.ent = a.ent + slot * a.ent_stride;
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
-        DevWave<FAST> w{a.P, TextView{a.G.t2 + 2 * ro, a.G.nm + ro, T}, TextView{a.G.t2 + 2 * qo, a.G.nm + qo, D}, iv, lane,
+        const bool nfree = !(a.G.hasN[r] | a.G.hasN[q]);
+        DevWave<FAST> w{a.P, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, a.P.mrd, nfree),
+                        qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, a.P.mrd, nfree), iv, lane,
                         lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
                         FAST ? a.G.kmS + 64 * qo : nullptr};
@@ -465,6 +468,7 @@ struct lzani_ctx {
     u64* d_nm = nullptr;
     u64* d_nmoff = nullptr;
     int* d_L = nullptr;
+    int* d_hasN = nullptr;
     u32* d_kmL = nullptr;     // k-mer arrays (fast path: mal, msl <= 15), 64 entries per nm word
     u32* d_kmS = nullptr;
     u64 total_nm = 0;
@@ -505,7 +509,8 @@ int fail(lzani_ctx* c, int code, const std::string& msg)
 
 void free_genomes(lzani_ctx* c)
 {
-    hipFree(c->d_t2); hipFree(c->d_nm); hipFree(c->d_nmoff); hipFree(c->d_L); hipFree(c->d_kmL); hipFree(c->d_kmS);
+    hipFree(c->d_t2); hipFree(c->d_nm); hipFree(c->d_nmoff); hipFree(c->d_L); hipFree(c->d_kmL); hipFree(c->d_kmS); hipFree(c->d_hasN);
+    c->d_hasN = nullptr;
     c->d_t2 = c->d_nm = c->d_nmoff = nullptr; c->d_L = nullptr; c->d_kmL = c->d_kmS = nullptr; c->kmers_ready = false;
     c->n = 0;
 }
@@ -531,7 +536,7 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     return LZANI_OK;
 }
 
-GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmoff, c->d_L, c->d_kmL, c->d_kmS}; }
+GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmoff, c->d_L, c->d_kmL, c->d_kmS, c->d_hasN}; }
 
 // Index build of `rows` references (device list d_ref_ids) into slots 0..rows-1.
 int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
@@ -770,6 +775,8 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
     HIPCHK(c, hipMalloc(&c->d_nm, total_nm * 8));
     HIPCHK(c, hipMalloc(&c->d_nmoff, (size_t)n * 8));
     HIPCHK(c, hipMalloc(&c->d_L, (size_t)n * 4));
+    HIPCHK(c, hipMalloc(&c->d_hasN, (size_t)n * 4));
+    HIPCHK(c, hipMemset(c->d_hasN, 0, (size_t)n * 4));
     c->total_nm = total_nm;
     if (c->P.mal <= 15 && c->P.msl <= 15) {
         HIPCHK(c, hipMalloc(&c->d_kmL, total_nm * 64 * 4));
@@ -799,7 +806,7 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
     for (u32 g0 = 0; g0 < n; g0 += 32768) {
         u32 cnt = std::min<u32>(32768, n - g0);
         hipLaunchKernelGGL(k_pack, dim3((u32)((maxblk + 127) / 128), cnt), dim3(128), 0, c->stream,
-                           d_codes, d_codeoff + g0, c->d_t2, c->d_nm, c->d_nmoff + g0, c->d_L + g0, c->P.mrd, cnt);
+                           d_codes, d_codeoff + g0, c->d_t2, c->d_nm, c->d_nmoff + g0, c->d_L + g0, c->d_hasN + g0, c->P.mrd, cnt);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));

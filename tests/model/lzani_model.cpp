@@ -22,13 +22,17 @@ struct Genome {
     std::vector<u64> t2, nm;
     std::vector<u32> dirz, ent;
     IndexView iv;
-    TextView rview() const { return TextView{t2.data(), nm.data(), T}; }
-    TextView qview() const { return TextView{t2.data(), nm.data(), D}; }
+    int mrd;
+    bool nfree;
+    TextView rview() const { return ref_view(t2.data(), nm.data(), L, mrd, nfree); }
+    TextView qview() const { return qry_view(t2.data(), nm.data(), L, mrd, nfree); }
 };
 
 void pack_genome(Genome& g, const uint8_t* codes, int L, const Params& P)
 {
-    g.L = L; g.T = ref_text_len(L, P.mrd); g.D = L + P.mrd;
+    g.L = L; g.T = ref_text_len(L, P.mrd); g.D = L + P.mrd; g.mrd = P.mrd;
+    g.nfree = true;
+    for (int j = 0; j < L; ++j) if (codes[j] >= 4) g.nfree = false;
     size_t w2 = text_words2(g.T), wn = text_wordsN(g.T);
     g.t2.assign(w2, 0);
     g.nm.assign(wn, ~0ULL);
