@@ -205,7 +205,8 @@ __global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, 
 // ------------------------------------------------------------------------------------------
 // k_pairs: the pair kernel.
 // ------------------------------------------------------------------------------------------
-enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS, NQUEUES = 8 };
+enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS, SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5),
+       SEED_LDS_WORDS = SEED_SLOTS + 256 + SEED_BM_WORDS, NQUEUES = 8 };
 
 template <bool FAST>
 struct DevWave {
@@ -216,6 +217,7 @@ struct DevWave {
     u32* heads;      // per-wave LDS: SEED_SLOTS chain heads
     u32* nexts;      // 128 chain links
     u32* keys;       // 128 window msl-mers
+    u32* bitmap;     // SEED_BM_WORDS words, all zero between rounds
     const u32* rkS;  // FAST: msl-mers of the reference text, one per position
     const u32* qkL;  // FAST: hashed mal-mers of the query text
     const u32* qkS;  // FAST: msl-mers of the query text
@@ -244,58 +246,67 @@ struct DevWave {
         bool mm = lane < n && !sym_match(R, r0 - 1 - lane, Q, q0 - 1 - lane);
         return __ballot(mm);
     }
-    // Close-seed search of all tracking lanes of a round at once.  The <= 128 window positions
-    // [r_end, r_end + W) are hashed by their msl-mer into a per-wave LDS table (two lanes-passes),
-    // every tracking lane then walks the one chain of its own msl-mer and collects the matching
-    // positions below its own window limit into a 128-bit mask; candidates are taken in ascending
-    // position, which is the order of the reference's ht_short bucket (parser.cpp:555-579).
-    __device__ __forceinline__ void seed_join(int i, int nt, int r_end, int lit, int W, int& sp, int& sl) const
+    // Close-seed search of all tracking lanes of a round at once (replaces the ht_short bucket walk,
+    // parser.cpp:548-580).  rk0/rk1 = msl-mers of the window positions r_end+lane / r_end+64+lane,
+    // qk = msl-mer of this lane's step (KM_INVALID where there is none).
+    //  1. prefilter: the window k-mers set bits in a per-wave 16 Kbit LDS bitmap (exact for msl <= 7,
+    //     a Bloom filter above), each tracking lane tests its own k-mer; in four rounds out of five no
+    //     lane hits and the search ends here (the bits are cleared again, the bitmap is always zero
+    //     between rounds);
+    //  2. otherwise the window k-mers are chained into a small LDS hash table and every hit lane
+    //     walks the chain of its k-mer, collecting the matching positions below its own window limit
+    //     into a 128-bit mask; candidates are then taken in ascending position, the order of the
+    //     reference's bucket.
+    __device__ __forceinline__ u32 bm_hash(u32 k) const
+    {
+        return P.msl <= 7 ? k : (k * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
+    }
+    __device__ __forceinline__ void seed_join(int i, int r_end, int lit, u32 rk0, u32 rk1, u32 qk, int& sp, int& sl) const
     {
         sp = 0; sl = 0;
         const u32 EMPTY = 0xFFFFFFFFu;
+        const u32 b0 = bm_hash(rk0), b1 = bm_hash(rk1), bq = bm_hash(qk);
+        if (rk0 != KM_INVALID) atomicOr(&bitmap[b0 >> 5], 1u << (b0 & 31));
+        if (rk1 != KM_INVALID) atomicOr(&bitmap[b1 >> 5], 1u << (b1 & 31));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool hit = false;
+        if (qk != KM_INVALID) hit = (bitmap[bq >> 5] >> (bq & 31)) & 1u;
+        const u64 any = __ballot(hit);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (rk0 != KM_INVALID) bitmap[b0 >> 5] = 0;
+        if (rk1 != KM_INVALID) bitmap[b1 >> 5] = 0;
+        if (!any) return;
+
         for (int k = 0; k < SEED_SLOTS / 64; ++k) heads[lane + 64 * k] = EMPTY;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int pass = 0; pass < 2; ++pass) {
-            int idx = lane + 64 * pass;
-            u64 rk = 0;
-            bool ok = false;
-            if (idx < W) {
-                if (FAST) { u32 v = rkS[r_end + idx]; ok = v != KM_INVALID; rk = v; }
-                else ok = kmer_at(R, r_end + idx, P.msl, rk);
-            }
-            if (ok) {
-                u32 slot = ((u32)rk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS);
-                keys[idx] = (u32)rk;
-                nexts[idx] = atomicExch(&heads[slot], (u32)idx);
-            }
+        if (rk0 != KM_INVALID) {
+            keys[lane] = rk0;
+            nexts[lane] = atomicExch(&heads[(rk0 * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)], (u32)lane);
+        }
+        if (rk1 != KM_INVALID) {
+            keys[lane + 64] = rk1;
+            nexts[lane + 64] = atomicExch(&heads[(rk1 * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)], (u32)lane + 64);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        u64 qk = 0;
-        bool qok = false;
-        if (lane < nt) {
-            if (FAST) { u32 v = qkS[i + lane]; qok = v != KM_INVALID; qk = v; }
-            else qok = kmer_at(Q, i + lane, P.msl, qk);
-        }
-        if (qok) {
+        if (hit) {
             const u32 lim = (u32)(lit + lane + P.mrd);          // this step's window is [0, lim)
             u64 c0 = 0, c1 = 0;
-            u32 slot = ((u32)qk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS);
             int guard = 0;
-            for (u32 h = heads[slot]; h != EMPTY; h = nexts[h]) {
+            for (u32 h = heads[(qk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)]; h != EMPTY; h = nexts[h]) {
                 if (++guard > 128) { LZ_GUARD_TRIP(4); break; }
-                if (keys[h] == (u32)qk && h < lim) {
-                    if (h < 64) c0 |= 1ULL << h; else c1 |= 1ULL << (h - 64);
-                }
+                const u64 bit = (u64)(keys[h] == qk && h < lim) << (h & 63);
+                c0 |= h < 64 ? bit : 0;
+                c1 |= h < 64 ? 0 : bit;
             }
             const int ref_pred = r_end + lit + lane;
-            while (c0) {
-                int idx = ctz64(c0); c0 &= c0 - 1;
-                seed_consider(r_end + idx, equal_len(R, r_end + idx, Q, i + lane, P.msl), ref_pred, sp, sl);
-            }
-            while (c1) {
-                int idx = 64 + ctz64(c1); c1 &= c1 - 1;
+            while (c0 | c1) {
+                int idx;
+                if (c0) { idx = ctz64(c0); c0 &= c0 - 1; }
+                else { idx = 64 + ctz64(c1); c1 &= c1 - 1; }
                 seed_consider(r_end + idx, equal_len(R, r_end + idx, Q, i + lane, P.msl), ref_pred, sp, sl);
             }
         }
@@ -306,20 +317,28 @@ struct DevWave {
                                                int& ev_lane, int& bpos, int& blen) const
     {
         int bp = 0, bl = 0;
+        const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
+        const int W = nt > 0 ? imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end) : 0;
+        const bool join = FAST && nt > 0 && W > 0 && W <= 128;     // wave-uniform
+        // issue every independent load of the round first
+        u32 hq = KM_INVALID, rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
+        if (FAST) {
+            if (lane < n) hq = qkL[i + lane];
+            if (join) {
+                if (lane < nt) qk = qkS[i + lane];
+                if (lane < W) rk0 = rkS[r_end + lane];
+                if (lane + 64 < W) rk1 = rkS[r_end + 64 + lane];
+            }
+        }
         if (lane < n) {
-            if (FAST) {
-                u32 h = qkL[i + lane];
-                if (h != KM_INVALID) anchor_lookup(P, R, Q, I, h, i + lane, bp, bl);
-            } else best_anchor(P, R, Q, I, i + lane, bp, bl);
+            if (FAST) { if (hq != KM_INVALID) anchor_lookup(P, R, Q, I, hq, i + lane, bp, bl); }
+            else best_anchor(P, R, Q, I, i + lane, bp, bl);
         }
         stamp(2);
-        const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
         if (nt > 0) {                                                // wave-uniform
             int sp = 0, sl = 0;
-            const int W = imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end);
-            if (W > 128 || P.msl > 16) {
-                if (lane < nt) seed_search_window(P, R, Q, i + lane, r_end, lit + lane, sp, sl);
-            } else if (W > 0) seed_join(i, nt, r_end, lit, W, sp, sl);
+            if (join) seed_join(i, r_end, lit, rk0, rk1, qk, sp, sl);
+            else if (W > 0 && lane < nt) seed_search_window(P, R, Q, i + lane, r_end, lit + lane, sp, sl);
             if (lane < nt) {
                 arbitrate(P, R.len, lit + lane, bp, bl, sp, sl);
                 bp = sp; bl = sl;
@@ -385,8 +404,9 @@ template <bool FAST>
 __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 {
     const int lane = threadIdx.x & 63;
-    __shared__ u32 s_seed[4][SEED_SLOTS + 256];
+    __shared__ u32 s_seed[4][SEED_LDS_WORDS];
     u32* const lds = s_seed[threadIdx.x >> 6];
+    for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[SEED_SLOTS + 256 + k] = 0;
     u32 qx = xcc_id() % NQUEUES, dry = 0;
     for (;;) {
         // One ticket per wave.  NB: this is the only lane-dependent branch of the persistent loop.
@@ -425,7 +445,7 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         const bool nfree = !(a.G.hasN[r] | a.G.hasN[q]);
         DevWave<FAST> w{a.P, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, a.P.mrd, nfree),
                         qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, a.P.mrd, nfree), iv, lane,
-                        lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128,
+                        lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128, lds + SEED_SLOTS + 256,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
                         FAST ? a.G.kmS + 64 * qo : nullptr};
         PairMachine<DevWave<FAST>> m(w, a.P, T, D);
