@@ -261,9 +261,9 @@ struct DevWave {
     {
         return P.msl <= 7 ? k : (k * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
     }
-    __device__ __forceinline__ void seed_join(int i, int r_end, int lit, u32 rk0, u32 rk1, u32 qk, int& sp, int& sl) const
+    __device__ __forceinline__ void seed_join(int lit, u32 rk0, u32 rk1, u32 qk, u64& c0, u64& c1) const
     {
-        sp = 0; sl = 0;
+        c0 = 0; c1 = 0;
         const u32 EMPTY = 0xFFFFFFFFu;
         const u32 b0 = bm_hash(rk0), b1 = bm_hash(rk1), bq = bm_hash(qk);
         if (rk0 != KM_INVALID) atomicOr(&bitmap[b0 >> 5], 1u << (b0 & 31));
@@ -294,7 +294,6 @@ struct DevWave {
         __builtin_amdgcn_wave_barrier();
         if (hit) {
             const u32 lim = (u32)(lit + lane + P.mrd);          // this step's window is [0, lim)
-            u64 c0 = 0, c1 = 0;
             int guard = 0;
             for (u32 h = heads[(qk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)]; h != EMPTY; h = nexts[h]) {
                 if (++guard > 128) { LZ_GUARD_TRIP(4); break; }
@@ -302,55 +301,112 @@ struct DevWave {
                 c0 |= h < 64 ? bit : 0;
                 c1 |= h < 64 ? 0 : bit;
             }
-            const int ref_pred = r_end + lit + lane;
-            while (c0 | c1) {
-                int idx;
-                if (c0) { idx = ctz64(c0); c0 &= c0 - 1; }
-                else { idx = 64 + ctz64(c1); c1 &= c1 - 1; }
-                seed_consider(r_end + idx, equal_len(R, r_end + idx, Q, i + lane, P.msl), ref_pred, sp, sl);
-            }
         }
         __builtin_amdgcn_wave_barrier();
     }
 
-    __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit,
-                                               int& ev_lane, int& bpos, int& blen) const
+    __device__ __forceinline__ u64 bcast64(u64 v, int l) const      // readlane returns a signed int: widen as u32
+    {
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+        return ((u64)hi << 32) | lo;
+    }
+    // equal_len by the whole wave: 64 symbols per step (ballot + ctz), same value as lzani::equal_len
+    __device__ __forceinline__ int wave_equal_len(int rp, int qp, int start) const
+    {
+        const int bound = imin(R.len - rp, Q.len - qp);
+        int n = start;
+        while (n < bound) {
+            u64 B = mism_fwd(qp + n, rp + n, imin(64, bound - n));
+            if (B) { n += ctz64(B); break; }
+            n += 64;
+        }
+        n = imin(n, bound);
+        return n > start ? n : start;
+    }
+
+    // Generic round: every lane evaluates its step completely (portable code of lzani_core.h).
+    __device__ __forceinline__ bool find_event_generic(int i, int n, bool trk, int r_end, int lit,
+                                                       int& ev_lane, int& bpos, int& blen) const
     {
         int bp = 0, bl = 0;
-        const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
-        const int W = nt > 0 ? imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end) : 0;
-        const bool join = FAST && nt > 0 && W > 0 && W <= 128;     // wave-uniform
-        // issue every independent load of the round first
-        u32 hq = KM_INVALID, rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
-        if (FAST) {
-            if (lane < n) hq = qkL[i + lane];
-            if (join) {
-                if (lane < nt) qk = qkS[i + lane];
-                if (lane < W) rk0 = rkS[r_end + lane];
-                if (lane + 64 < W) rk1 = rkS[r_end + 64 + lane];
-            }
-        }
-        if (lane < n) {
-            if (FAST) { if (hq != KM_INVALID) anchor_lookup(P, R, Q, I, hq, i + lane, bp, bl); }
-            else best_anchor(P, R, Q, I, i + lane, bp, bl);
-        }
-        stamp(2);
-        if (nt > 0) {                                                // wave-uniform
-            int sp = 0, sl = 0;
-            if (join) seed_join(i, r_end, lit, rk0, rk1, qk, sp, sl);
-            else if (W > 0 && lane < nt) seed_search_window(P, R, Q, i + lane, r_end, lit + lane, sp, sl);
-            if (lane < nt) {
-                arbitrate(P, R.len, lit + lane, bp, bl, sp, sl);
-                bp = sp; bl = sl;
-            }
-        }
+        if (lane < n)
+            eval_step(P, R, Q, I, i + lane, trk && (lit + lane <= P.mqd), r_end, lit + lane, bp, bl);
         u64 hit = __ballot(lane < n && bl >= P.msl);
-        stamp(7);
         if (!hit) return false;
         ev_lane = ctz64(hit);
         bpos = __builtin_amdgcn_readlane(bp, ev_lane);     // ev_lane is wave-uniform (from the ballot)
         blen = __builtin_amdgcn_readlane(bl, ev_lane);
         return true;
+    }
+
+    // Fast round (k-mer words available, seed window <= 128): the lanes only DETECT candidates --
+    // a bucket entry whose tag equals the step's mal-mer, a window position whose msl-mer equals the
+    // step's -- and the wave then verifies the candidates of the first candidate lane together
+    // (wave_equal_len), exactly as eval_step would for that step; if that step turns out not to hit
+    // (quirk Q1, or mal < msl) the next candidate lane is taken.
+    __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit,
+                                               int& ev_lane, int& bpos, int& blen) const
+    {
+        const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
+        const int W = nt > 0 ? imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end) : 0;
+        const int tb = I.kb - I.dirbits;
+        if (!FAST || W > 128 || I.tagmask != (u32)lowmask(tb))          // the stored tag must identify the k-mer
+            return find_event_generic(i, n, trk, r_end, lit, ev_lane, bpos, blen);
+
+        // every independent load of the round first
+        u32 hq = KM_INVALID, rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
+        if (lane < n) hq = qkL[i + lane];
+        if (W > 0) {
+            if (lane < nt) qk = qkS[i + lane];
+            if (lane < W) rk0 = rkS[r_end + lane];
+            if (lane + 64 < W) rk1 = rkS[r_end + 64 + lane];
+        }
+        // anchor candidates: first bucket entry with this step's tag, and how many follow
+        u32 aj = 0, ac = 0;
+        if (hq != KM_INVALID) {
+            const u32 b = hq >> tb, tag = hq & I.tagmask;
+            u32 s = I.dirz[b], e = I.dirz[b + 1];
+            if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
+            for (u32 j = s; j < e; ++j) {
+                const bool m = (I.ent[j] >> I.posbits) == tag;
+                aj = (m && ac == 0) ? j : aj;
+                ac += m;
+            }
+        }
+        stamp(2);
+        u64 c0 = 0, c1 = 0;
+        if (W > 0) seed_join(lit, rk0, rk1, qk, c0, c1);
+        u64 todo = __ballot(ac != 0 || (c0 | c1) != 0);
+        stamp(7);
+        const u32 pm = (u32)lowmask(I.posbits);
+        while (todo) {
+            const int l = ctz64(todo);
+            todo &= todo - 1;
+            const int qp = i + l;
+            int ap = 0, al = 0;
+            const u32 j0 = __builtin_amdgcn_readlane(aj, l), cnt = __builtin_amdgcn_readlane(ac, l);
+            for (u32 k = 0; k < cnt; ++k) {                          // same k-mer, ascending position
+                const int p = (int)(I.ent[j0 + k] & pm);
+                const int m = wave_equal_len(p, qp, 0);
+                if (m >= P.mal && m > al) { al = m; ap = p; }
+            }
+            int bp = ap, bl = al;
+            if (l < nt) {
+                int sp = 0, sl = 0;
+                const int ref_pred = r_end + lit + l;
+                u64 d0 = bcast64(c0, l), d1 = bcast64(c1, l);
+                while (d0 | d1) {
+                    int idx;
+                    if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
+                    else { idx = 64 + ctz64(d1); d1 &= d1 - 1; }
+                    seed_consider(r_end + idx, wave_equal_len(r_end + idx, qp, P.msl), ref_pred, sp, sl);
+                }
+                arbitrate(P, R.len, lit + l, ap, al, sp, sl);
+                bp = sp; bl = sl;
+            }
+            if (bl >= P.msl) { ev_lane = l; bpos = bp; blen = bl; return true; }
+        }
+        return false;
     }
     __device__ __forceinline__ ExtMasks ext_scan(u64 prevB, u64 B, int n) const
     {
