@@ -361,16 +361,27 @@ struct DevWave {
             if (lane < W) rk0 = rkS[r_end + lane];
             if (lane + 64 < W) rk1 = rkS[r_end + 64 + lane];
         }
-        // anchor candidates: first bucket entry with this step's tag, and how many follow
+        // anchor candidates: first bucket entry with this step's tag, and how many follow.  Buckets
+        // hold ~0.6 entries: the first four are fetched at once (clamped indices, one wait), a loop
+        // only serves the rare longer bucket.
         u32 aj = 0, ac = 0;
         if (hq != KM_INVALID) {
             const u32 b = hq >> tb, tag = hq & I.tagmask;
             u32 s = I.dirz[b], e = I.dirz[b + 1];
             if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
-            for (u32 j = s; j < e; ++j) {
-                const bool m = (I.ent[j] >> I.posbits) == tag;
-                aj = (m && ac == 0) ? j : aj;
-                ac += m;
+            const u32 cnt = e - s;
+            if (cnt) {
+                const u32 last = e - 1;
+                const u32 e0 = I.ent[s], e1 = I.ent[min(s + 1, last)], e2 = I.ent[min(s + 2, last)], e3 = I.ent[min(s + 3, last)];
+                const bool m0 = (e0 >> I.posbits) == tag, m1 = cnt > 1 && (e1 >> I.posbits) == tag,
+                           m2 = cnt > 2 && (e2 >> I.posbits) == tag, m3 = cnt > 3 && (e3 >> I.posbits) == tag;
+                ac = (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
+                aj = s + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
+                for (u32 j = s + 4; j < e; ++j) {
+                    const bool m = (I.ent[j] >> I.posbits) == tag;
+                    aj = (m && ac == 0) ? j : aj;
+                    ac += m;
+                }
             }
         }
         stamp(2);
