@@ -467,9 +467,13 @@ __device__ __forceinline__ u32 xcc_id()
     return x & 7u;
 }
 
-template <bool FAST>
+// Instantiations: FAST = per-genome k-mer words exist (mal, msl <= 15); NFREE = no genome of the
+// context holds an N (the N mask is never consulted); DEFP = the LZ parameters are the reference's
+// defaults (params.h:34-48), folded into the code as constants.
+template <bool FAST, bool NFREE, bool DEFP>
 __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 {
+    const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
     const int lane = threadIdx.x & 63;
     __shared__ u32 s_seed[4][SEED_LDS_WORDS];
     u32* const lds = s_seed[threadIdx.x >> 6];
@@ -504,18 +508,18 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 
         const int Lr = a.G.L[r], Lq = a.G.L[q];
         const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
-        const int T = ref_text_len(Lr, a.P.mrd), D = Lq + a.P.mrd;
+        const int T = ref_text_len(Lr, Pk.mrd), D = Lq + Pk.mrd;
         IndexView iv;
         iv.dirz = a.dirz + slot * a.dir_stride;
         iv.ent = a.ent + slot * a.ent_stride;
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
-        const bool nfree = !(a.G.hasN[r] | a.G.hasN[q]);
-        DevWave<FAST> w{a.P, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, a.P.mrd, nfree),
-                        qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, a.P.mrd, nfree), iv, lane,
+        const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
+        DevWave<FAST> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
+                        qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
                         lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128, lds + SEED_SLOTS + 256,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
                         FAST ? a.G.kmS + 64 * qo : nullptr};
-        PairMachine<DevWave<FAST>> m(w, a.P, T, D);
+        PairMachine<DevWave<FAST>> m(w, Pk, T, D);
         int res[3];
 #ifdef LZANI_STAMPS
         for (int k = 0; k < 8; ++k) w.acc[k] = 0;
@@ -560,6 +564,7 @@ struct lzani_ctx {
     u32* d_kmS = nullptr;
     u64 total_nm = 0;
     bool kmers_ready = false;
+    bool all_nfree = false;       // no genome holds an N: the NFREE kernel instantiation applies
 
     u32* d_dirz = nullptr;
     u32* d_ent = nullptr;
@@ -741,8 +746,14 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             u64 waves = e1 - e0;
             u32 blocks = (u32)std::min<u64>((waves + 3) / 4, max_blocks);
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-            if (c->d_kmL) hipLaunchKernelGGL(k_pairs<true>, dim3(blocks), dim3(256), 0, c->stream, pa);
-            else hipLaunchKernelGGL(k_pairs<false>, dim3(blocks), dim3(256), 0, c->stream, pa);
+            const Params& q = c->P;
+            const bool defp = q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3;
+            const dim3 gd(blocks), bd(256);
+            if (!c->d_kmL) hipLaunchKernelGGL((k_pairs<false, false, false>), gd, bd, 0, c->stream, pa);
+            else if (c->all_nfree && defp) hipLaunchKernelGGL((k_pairs<true, true, true>), gd, bd, 0, c->stream, pa);
+            else if (c->all_nfree) hipLaunchKernelGGL((k_pairs<true, true, false>), gd, bd, 0, c->stream, pa);
+            else if (defp) hipLaunchKernelGGL((k_pairs<true, false, true>), gd, bd, 0, c->stream, pa);
+            else hipLaunchKernelGGL((k_pairs<true, false, false>), gd, bd, 0, c->stream, pa);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
             c->tm.pair_launches += 1;
@@ -897,6 +908,11 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        std::vector<int> hn(n);
+        HIPCHK(c, hipMemcpy(hn.data(), c->d_hasN, (size_t)n * 4, hipMemcpyDeviceToHost));
+        c->all_nfree = std::all_of(hn.begin(), hn.end(), [](int v) { return v == 0; });
+    }
     TRACE("set_genomes: n=%u Tmax=%d dirbits=%d posbits=%d tagmask=%x", n, c->Tmax, c->geo.dirbits, c->geo.posbits, c->geo.tagmask);
     hipFree(d_codes); hipFree(d_codeoff);
     return LZANI_OK;
