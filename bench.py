@@ -52,6 +52,20 @@ def algorithmic_bytes(lens, ref_ids, params):
     return tot
 
 
+def pmc_traffic(n, seed, world):
+    """HBM bytes per k_pairs launch from the committed rocprofv3 PMC passes (profiles/latest_pmc.json),
+    quoted only when they were collected on this very workload; PMC cannot be read from inside the run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_pmc.json")) as f:
+            rec = json.load(f)
+        w = rec["workload"]
+        if world == 1 and w["genomes"] == n and w["seed"] == seed:
+            return rec["traffic_bytes_fetch_doubled"]
+    except Exception:
+        pass
+    return None
+
+
 def host_cores():
     """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = os.cpu_count() or 1
@@ -193,7 +207,7 @@ def main():
                                    if world > 1 else "single GPU, all rows",
                        "params": params},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.seed, world),
                          "kernel": "k_pairs", "avg_launch_ms": avg_launch_ms, "launches_per_step": launches,
                          "algorithmic_bytes_per_launch": abytes / launches,
                          "index_build_ms_per_step": index_ms / args.steps},
