@@ -173,3 +173,52 @@ def test_full_size_properties_1000_genomes():
     for r, q in pairs:
         if r != q:
             assert tuple(res[r, q]) == O.oracle_pair(seqs[r], seqs[q]), (r, q)
+
+
+def test_long_genomes_config4_shape():
+    """BASELINE configs[3] in miniature: Mbp-scale genomes with --mal 15 --msl 9 --reg 60 (24-bit text
+    positions, 2^20+ bucket directory, several hundred extension chunks per match)."""
+    _, seqs = SG.make_set(6, 3, lmin=900_000, lmax=1_100_000, fam=3, dmin=0.005, dmax=0.08)
+    prm = dict(mal=15, msl=9, reg=60)
+    got = gpu_all2all(seqs, prm)
+    want = O.oracle_all2all(seqs, prm, threads=16)
+    bad = np.argwhere((got != want).any(axis=2))
+    assert len(bad) == 0, (bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
+    assert got[0, 1, 0] > 800_000          # related genomes really align over most of their length
+
+
+def test_filtered_heavy_tailed_rows_config5_shape():
+    """BASELINE configs[4] in miniature: a symmetric sparse pair list with heavy-tailed row sizes
+    (singletons, small and one large family plus random cross-family pairs), as a kmer-db prefilter gives."""
+    st = SG.Stream(44)
+    fams = [1] * 40 + [2] * 10 + [5] * 4 + [40]
+    seqs, fam_of = [], []
+    for f, size in enumerate(fams):
+        anc = (st.u64(st.randint(2500, 4000)) % np.uint64(4)).astype(np.uint8)
+        for m in range(size):
+            seqs.append(anc if m == 0 else SG.mutate(anc, 0.02 + 0.1 * st.one(), st))
+            fam_of.append(f)
+    n = len(seqs)
+    pairs = {(a, b) for a in range(n) for b in range(a + 1, n) if fam_of[a] == fam_of[b]}
+    while len(pairs) < 900 + 120:
+        a, b = st.randint(0, n - 1), st.randint(0, n - 1)
+        if a != b:
+            pairs.add((min(a, b), max(a, b)))
+    rows = [[] for _ in range(n)]
+    for a, b in sorted(pairs):
+        rows[a].append(b)
+        rows[b].append(a)
+    ref_ids = np.arange(n, dtype=np.uint32)
+    row_off = np.zeros(n + 1, dtype=np.uint64)
+    row_off[1:] = np.cumsum([len(r) for r in rows])
+    q = np.array([x for r in rows for x in r], dtype=np.uint32)
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    got = eng.run_rows(ref_ids, row_off, q)
+    eng.close()
+    assert max(len(r) for r in rows) >= 39 and min(len(r) for r in rows) <= 2
+    e = 0
+    for r in range(n):
+        for x in rows[r]:
+            assert tuple(got[e]) == O.oracle_pair(seqs[r], seqs[x]), (r, x)
+            e += 1
