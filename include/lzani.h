@@ -60,6 +60,14 @@ typedef struct lzani_timing {
     uint64_t pairs;             /* directed pairs processed                                 */
 } lzani_timing;
 
+/* One region of CParser::calc_regions / get_parsing (/root/reference/src/parser.cpp:786-837,
+ * region_t in defs.h:67-153): what --out-alignment prints (lz_matcher.cpp:102-169).  `pair` is the
+ * CSR position of the directed pair the region belongs to. */
+typedef struct lzani_region {
+    uint64_t pair;
+    int32_t  ref_start, ref_end, seq_start, seq_end, num_matches, num_mismatches;
+} lzani_region;
+
 typedef struct lzani_ctx lzani_ctx;
 
 void lzani_default_params(lzani_params *p);
@@ -90,6 +98,14 @@ int lzani_run_rows(lzani_ctx *ctx, uint32_t n_rows, const uint32_t *ref_ids, con
  * to row_off[n_rows] lzani_result records, e.g. the shard buffer handed to an RCCL gather. */
 int lzani_run_rows_device(lzani_ctx *ctx, uint32_t n_rows, const uint32_t *ref_ids, const uint64_t *row_off,
                           const uint32_t *query_ids, void *d_out);
+
+/* lzani_run_rows plus the per-pair regions (replaces parser.get_parsing() in the worker, lz_matcher.cpp:
+ * 222-223, 241-242).  Up to `capacity` regions are written to `regions` (host memory) in no particular
+ * order -- sort by (pair, length desc, seq_start) for the reference's per-pair order; *n_regions receives
+ * the number found, which may exceed capacity (then call again with a larger buffer). */
+int lzani_run_rows_regions(lzani_ctx *ctx, uint32_t n_rows, const uint32_t *ref_ids, const uint64_t *row_off,
+                           const uint32_t *query_ids, lzani_result *out, lzani_region *regions,
+                           uint64_t capacity, uint64_t *n_regions);
 
 int lzani_get_timing(const lzani_ctx *ctx, lzani_timing *t);
 

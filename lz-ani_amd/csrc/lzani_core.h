@@ -353,6 +353,31 @@ struct Regions {
     LZ_HD void seg_match_run(int n) { if (n > 0) { cl += n; clit += nl; nl = 0; } }
 };
 
+// calc_regions restated as a stream (parser.cpp:786-837): the region_t of the open region, fed with
+// the factors in emission order.  Only the alignment instantiation (ALN) of the machine uses it.
+struct RegionCoords {
+    int ref_start, ref_end, seq_start, seq_end, nm, nmm, buf;
+    bool fresh;                       // the next match factor is the region's match_distant
+    LZ_HD void clear() { ref_start = ref_end = seq_start = seq_end = -1; nm = nmm = buf = 0; fresh = true; }
+    LZ_HD int length() const { return seq_end - seq_start; }
+    LZ_HD void touch(int dp, int off, int len)
+    {
+        if (seq_start < 0 || dp < seq_start) seq_start = dp;
+        if (seq_end < 0 || dp + len > seq_end) seq_end = dp + len;
+        if (ref_start < 0 || off < ref_start) ref_start = off;
+        if (ref_end < 0 || off + len > ref_end) ref_end = off + len;
+    }
+    LZ_HD void match(int dp, int off, int len)
+    {
+        if (fresh) { clear(); fresh = false; }
+        else { ref_end += buf; seq_end += buf; nmm += buf; }          // extend_region + update_mismatches
+        buf = 0;
+        touch(dp, off, len);
+        nm += len;
+    }
+    LZ_HD void lit(int len) { buf += len; }
+};
+
 // Result of scanning one 64-symbol chunk of an approximate extension (try_extend_*,
 // parser.cpp:377-441).  prevB/B are mismatch masks of the previous/current chunk (bit j =
 // symbol j of the chunk; symbols before the start of the extension count as matches).
@@ -379,14 +404,35 @@ LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool
 //   ExtMasks ext_scan(prevB, B, n)
 //   int  best_split(Lm, Rm, to_scan) argmax_s popc(Lm & low(s)) + popc(Rm >> s), last max wins
 //   void stamp(section)             profiling hook (no-op outside the LZANI_STAMPS diagnostic build)
-template <class W>
+//   void emit_region(RegionCoords)  ALN only: one region of calc_regions (length >= reg)
+template <class W, bool ALN = false>
 struct PairMachine {
     W& w;
     const Params& P;
     const int T, D;
     Regions g;
+    RegionCoords c;
 
-    LZ_HD PairMachine(W& w_, const Params& P_, int T_, int D_) : w(w_), P(P_), T(T_), D(D_) { g.init(P_.reg); }
+    LZ_HD PairMachine(W& w_, const Params& P_, int T_, int D_) : w(w_), P(P_), T(T_), D(D_) { g.init(P_.reg); c.clear(); }
+
+    // ---- factor stream for the alignment output (ALN): runs of a match mask along one diagonal
+    LZ_HD void runs(u64 M, int n, int q0, int r0, int dp_shift)
+    {
+        int pos = 0;
+        while (pos < n) {
+            u64 rest = M >> pos;
+            if (!rest) { c.lit(n - pos); break; }
+            int z = ctz64(rest);
+            if (z) c.lit(z);
+            pos += z;
+            u64 inv = ~(M >> pos);
+            int len = inv ? ctz64(inv) : 64;
+            len = imin(len, n - pos);
+            c.match(q0 + pos - dp_shift, r0 + pos, len);
+            pos += len;
+        }
+    }
+    LZ_HD void region_close() { if (ALN) { if (!c.fresh && c.length() >= P.reg) w.emit_region(c); c.clear(); } }
 
     // compare_ranges folded (parser.cpp:210-248): any length, forward order
     LZ_HD void seg_range(int q0, int r0, int len)
@@ -395,7 +441,13 @@ struct PairMachine {
             int n = imin(64, len - base);
             u64 B = w.mism_fwd(q0 + base, r0 + base, n);
             g.seg(~B & lowmask(n), n);
+            if (ALN) runs(~B & lowmask(n), n, q0 + base, r0 + base, 0);
         }
+    }
+    LZ_HD void match_run(int dp, int off, int len)
+    {
+        g.seg_match_run(len);
+        if (ALN && len > 0) c.match(dp, off, len);
     }
 
     // try_extend_forward (parser.cpp:377-409) fused with the fold of compare_ranges(i, ref_pred, e)
@@ -423,6 +475,12 @@ struct PairMachine {
             g.cl += last - last_mm;
             g.clit += g.nl + last_mm;
             g.nl = 0;
+            if (ALN)
+                for (int base = 0; base < last; base += 64) {
+                    int n = imin(64, last - base);
+                    u64 B = w.mism_fwd(q0 + base, r0 + base, n);
+                    runs(~B & lowmask(n), n, q0 + base, r0 + base, 0);
+                }
         }
         return last;
     }
@@ -459,7 +517,21 @@ struct PairMachine {
             int s = w.best_split(Lm, Rm, to_scan);
             u64 right = (s >= 64) ? 0ULL : ((Rm >> s) << s);
             F = (Lm & lowmask(s)) | (right << shift);
-        }
+            if (ALN) {
+                // left part on the left diagonal, the untouched middle, right part on the right diagonal.
+                // Quirk of the reference (parser.cpp:353-358): when the first right symbol is a mismatch
+                // merged into a preceding literal run, data_p is not advanced, so every later factor of
+                // the right part carries a data_pos one too small.
+                if (s > 0) runs(Lm & lowmask(s), s, ds, r_left, 0);
+                if (shift > 0) c.lit(shift);
+                if (s < to_scan) {
+                    const bool first_match = (Rm >> s) & 1ULL;
+                    const bool prev_lit = shift > 0 || (s > 0 && !((Lm >> (s - 1)) & 1ULL));
+                    const int q = (!first_match && prev_lit) ? 1 : 0;
+                    runs(Rm >> s, to_scan - s, ds + s + shift, r_right_end - to_scan + s, q);
+                }
+            }
+        } else if (ALN) c.lit(len);
         g.seg(F, len);
     }
 
@@ -488,23 +560,25 @@ struct PairMachine {
             if (strk && iabs(bpos - ref_pred) <= P.mrd) {
                 // close match: fill the gap, then the match itself (parser.cpp:630-635; quirk Q2)
                 gap_fill(i - lit, r_end, bpos + blen, lit);
-                g.seg_match_run(blen);
+                match_run(i, bpos, blen);
             } else {
                 // distant match (parser.cpp:636-685)
                 int avail;
                 if (prev_rs >= 0 && prev_re - prev_rs < P.reg) {       // drop the short region
                     avail = pre_lit + (i - prev_rs);
                     g.discard();
+                    if (ALN) c.clear();
                     prev_rs = -1;
                 } else avail = lit;
                 int b = avail > 0 ? extend_backward(i, bpos, avail) : 0;
                 g.finalize();                                           // a match_distant factor follows
+                region_close();
                 if (b > 0) {
                     pre_lit = avail - b;
                     seg_range(i - b, bpos - b, b);
                     prev_rs = i - b;
                 } else { pre_lit = avail; prev_rs = i; }
-                g.seg_match_run(blen);
+                match_run(i, bpos, blen);
             }
             i += blen;
             r_end = bpos + blen;
@@ -519,6 +593,7 @@ struct PairMachine {
         if (trk)   // tail compare against r_end - msl (parser.cpp:713, quirk Q3)
             seg_range(i - lit, r_end - P.msl, lit + (D - i));
         g.finalize();
+        region_close();
         out[0] = g.tm; out[1] = g.tl; out[2] = g.tc;
     }
 };

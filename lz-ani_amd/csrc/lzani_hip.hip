@@ -221,6 +221,23 @@ struct DevWave {
     const u32* rkS;  // FAST: msl-mers of the reference text, one per position
     const u32* qkL;  // FAST: hashed mal-mers of the query text
     const u32* qkS;  // FAST: msl-mers of the query text
+    // alignment instantiation: region sink
+    lzani_region* reg_out;
+    unsigned long long* reg_count;
+    unsigned long long reg_cap, pair_e;
+    __device__ __forceinline__ void emit_region(const RegionCoords& c) const
+    {
+        // one slot per wave without a lane-dependent branch (see the note at the ticket fetch)
+        const unsigned long long old = atomicAdd(reg_count, lane == 0 ? 1ULL : 0ULL);
+        const u32 lo = __builtin_amdgcn_readfirstlane((u32)old), hi = __builtin_amdgcn_readfirstlane((u32)(old >> 32));
+        const unsigned long long slot = ((unsigned long long)hi << 32) | lo;
+        if (slot < reg_cap) {
+            lzani_region* o = reg_out + slot;
+            o->pair = pair_e;
+            o->ref_start = c.ref_start; o->ref_end = c.ref_end; o->seq_start = c.seq_start; o->seq_end = c.seq_end;
+            o->num_matches = c.nm; o->num_mismatches = c.nmm;
+        }
+    }
 #ifdef LZANI_STAMPS
     // diagnostic build only: cycles per section, summed per wave, added to g_stamp_acc at pair end
     mutable unsigned long long t0;
@@ -458,6 +475,9 @@ struct PairArgs {
     const u64* qcum;
     u32 qb[NQUEUES + 1];
     unsigned long long* cursor;   // NQUEUES tickets counters
+    lzani_region* reg_out;        // alignment instantiation only
+    unsigned long long* reg_count;
+    unsigned long long reg_cap;
 };
 
 __device__ __forceinline__ u32 xcc_id()
@@ -470,7 +490,8 @@ __device__ __forceinline__ u32 xcc_id()
 // Instantiations: FAST = per-genome k-mer words exist (mal, msl <= 15); NFREE = no genome of the
 // context holds an N (the N mask is never consulted); DEFP = the LZ parameters are the reference's
 // defaults (params.h:34-48), folded into the code as constants.
-template <bool FAST, bool NFREE, bool DEFP>
+// ALN = also emit the regions of every pair (--out-alignment).
+template <bool FAST, bool NFREE, bool DEFP, bool ALN = false>
 __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 {
     const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
@@ -518,8 +539,8 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
                         qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
                         lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128, lds + SEED_SLOTS + 256,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
-                        FAST ? a.G.kmS + 64 * qo : nullptr};
-        PairMachine<DevWave<FAST>> m(w, Pk, T, D);
+                        FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
+        PairMachine<DevWave<FAST>, ALN> m(w, Pk, T, D);
         int res[3];
 #ifdef LZANI_STAMPS
         for (int k = 0; k < 8; ++k) w.acc[k] = 0;
@@ -663,8 +684,10 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
     return LZANI_OK;
 }
 
+struct RegionSink { lzani_region* d_regions; unsigned long long* d_count; unsigned long long capacity; };
+
 int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_off, const u32* query_ids,
-                  int* d_out)
+                  int* d_out, const RegionSink* rs = nullptr)
 {
     if (!c->n) return fail(c, LZANI_ERR_STATE, "lzani_run_rows: no genomes set");
     c->tm = lzani_timing{};
@@ -749,7 +772,10 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             const Params& q = c->P;
             const bool defp = q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3;
             const dim3 gd(blocks), bd(256);
-            if (!c->d_kmL) hipLaunchKernelGGL((k_pairs<false, false, false>), gd, bd, 0, c->stream, pa);
+            pa.reg_out = rs ? rs->d_regions : nullptr; pa.reg_count = rs ? rs->d_count : nullptr; pa.reg_cap = rs ? rs->capacity : 0;
+            if (rs && c->d_kmL) hipLaunchKernelGGL((k_pairs<true, false, false, true>), gd, bd, 0, c->stream, pa);
+            else if (rs) hipLaunchKernelGGL((k_pairs<false, false, false, true>), gd, bd, 0, c->stream, pa);
+            else if (!c->d_kmL) hipLaunchKernelGGL((k_pairs<false, false, false>), gd, bd, 0, c->stream, pa);
             else if (c->all_nfree && defp) hipLaunchKernelGGL((k_pairs<true, true, true>), gd, bd, 0, c->stream, pa);
             else if (c->all_nfree) hipLaunchKernelGGL((k_pairs<true, true, false>), gd, bd, 0, c->stream, pa);
             else if (defp) hipLaunchKernelGGL((k_pairs<true, false, true>), gd, bd, 0, c->stream, pa);
@@ -943,6 +969,37 @@ int lzani_run_rows(lzani_ctx* c, uint32_t n_rows, const uint32_t* ref_ids, const
         if (e != hipSuccess) rc = fail(c, LZANI_ERR_DEVICE, std::string("copy results: ") + hipGetErrorString(e));
     }
     hipFree(d_out);
+    return rc;
+}
+
+int lzani_run_rows_regions(lzani_ctx* c, uint32_t n_rows, const uint32_t* ref_ids, const uint64_t* row_off,
+                           const uint32_t* query_ids, lzani_result* out, lzani_region* regions,
+                           uint64_t capacity, uint64_t* n_regions)
+{
+    if (!c) return LZANI_ERR_ARG;
+    if (!ref_ids || !row_off || !n_regions || (capacity && !regions))
+        return fail(c, LZANI_ERR_ARG, "lzani_run_rows_regions: null argument");
+    const u64 n_pairs = n_rows ? row_off[n_rows] : 0;
+    if (n_pairs && !out) return fail(c, LZANI_ERR_ARG, "lzani_run_rows_regions: null output");
+    *n_regions = 0;
+    HIPCHK(c, hipSetDevice(c->dev));
+    int* d_out = nullptr;
+    RegionSink rs{nullptr, nullptr, capacity};
+    if (n_pairs) HIPCHK(c, hipMalloc(&d_out, n_pairs * sizeof(lzani_result)));
+    HIPCHK(c, hipMalloc(&rs.d_regions, std::max<uint64_t>(capacity, 1) * sizeof(lzani_region)));
+    HIPCHK(c, hipMalloc(&rs.d_count, sizeof(unsigned long long)));
+    HIPCHK(c, hipMemset(rs.d_count, 0, sizeof(unsigned long long)));
+    int rc = run_rows_impl(c, n_rows, ref_ids, row_off, query_ids, d_out, &rs);
+    if (rc == LZANI_OK) {
+        unsigned long long cnt = 0;
+        hipError_t e = hipMemcpy(&cnt, rs.d_count, sizeof cnt, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_pairs) e = hipMemcpy(out, d_out, n_pairs * sizeof(lzani_result), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && cnt && capacity)
+            e = hipMemcpy(regions, rs.d_regions, std::min<uint64_t>(cnt, capacity) * sizeof(lzani_region), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, LZANI_ERR_DEVICE, std::string("copy regions: ") + hipGetErrorString(e));
+        *n_regions = cnt;
+    }
+    hipFree(d_out); hipFree(rs.d_regions); hipFree(rs.d_count);
     return rc;
 }
 

@@ -72,7 +72,7 @@ static void usage()
          << "Options - output specification:\n"
          << "  -o, --out <file_name>          - output file name\n"
          << "      --out-ids <file_name>      - output file name for ids file (optional)\n"
-         << "      --out-alignment <file_name>- output file name for ids file (optional; not available in the GPU build yet)\n"
+         << "      --out-alignment <file_name>- output file name for ids file (optional)\n"
          << "      --out-in-percent <bool>    - output in percent (default: false)\n"
          << "      --out-type <type>          - one of:\n"
          << "                                   tsv - two tsv files with: results defined by --out-format and sequence ids (default)\n"
@@ -210,6 +210,8 @@ struct Engine {
     int (*set_genomes)(lzani_ctx*, uint32_t, const uint8_t* const*, const uint32_t*) = nullptr;
     int (*run_rows)(lzani_ctx*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, lzani_result*) = nullptr;
     int (*get_timing)(const lzani_ctx*, lzani_timing*) = nullptr;
+    int (*run_rows_regions)(lzani_ctx*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, lzani_result*, lzani_region*,
+                            uint64_t, uint64_t*) = nullptr;
     bool load(const char* argv0)
     {
         vector<string> cand;
@@ -224,13 +226,62 @@ struct Engine {
 #define BIND(f, n) f = reinterpret_cast<decltype(f)>(dlsym(so, n)); if (!f) { cerr << "Missing symbol " << n << endl; return false; }
         BIND(create, "lzani_create") BIND(destroy, "lzani_destroy") BIND(last_error, "lzani_last_error")
         BIND(set_genomes, "lzani_set_genomes") BIND(run_rows, "lzani_run_rows") BIND(get_timing, "lzani_get_timing")
+        BIND(run_rows_regions, "lzani_run_rows_regions")
 #undef BIND
         return true;
     }
 };
 
 // do_matching (lz_matcher.cpp:172-277): rows -> engine(s) -> results[ref] sorted by id
-static bool do_matching(const Engine& E, const vector<Genome>& g, const Filter& flt, ResultRows& results)
+struct AlnRegion { uint32_t ref, qry; lzani_region r; };
+
+// store_alignment (lz_matcher.cpp:102-169): one BLAST-tab-like row per region; rows of one pair in
+// calc_regions order (length desc, seq_start asc), pairs in (reference, query) order.
+static bool store_alignment(const vector<Genome>& g, vector<AlnRegion>& regs)
+{
+    ofstream o(P.out_aln, ios::binary);
+    if (!o.is_open()) { cerr << "Cannot open output file: " << P.out_aln << endl; return false; }
+    o << "query\treference\tpident\talnlen\tqstart\tqend\trstart\trend\tnt_match\tnt_mismatch\n";
+    sort(regs.begin(), regs.end(), [](const AlnRegion& a, const AlnRegion& b) {
+        if (a.ref != b.ref) return a.ref < b.ref;
+        if (a.qry != b.qry) return a.qry < b.qry;
+        int la = a.r.seq_end - a.r.seq_start, lb = b.r.seq_end - b.r.seq_start;
+        if (la != lb) return la > lb;
+        return a.r.seq_start < b.r.seq_start;
+    });
+    string line;
+    char num[64];
+    for (size_t k = 0; k < regs.size();) {
+        size_t k1 = k;
+        long mat = 0, lit = 0;
+        while (k1 < regs.size() && regs[k1].ref == regs[k].ref && regs[k1].qry == regs[k].qry) { mat += regs[k1].r.num_matches; lit += regs[k1].r.num_mismatches; ++k1; }
+        const uint32_t r = regs[k].ref, q = regs[k].qry;
+        const int len1 = (int)g[r].codes.size(), len2 = (int)g[q].codes.size();
+        bool keep = true;
+        if (P.flt_mask != 0) {                                  // the part of --out-filter that applies here (124-137)
+            double gani = (double)mat / len2, ani = mat + lit != 0 ? (double)mat / (mat + lit) : 0, qcov = (double)(mat + lit) / len2;
+            keep = !(gani < P.flt_vals[(int)Comp::gani]) && !(ani < P.flt_vals[(int)Comp::ani]) && !(qcov < P.flt_vals[(int)Comp::qcov]);
+        }
+        const int rc_corr = 2 * len1 + 2 * P.lz.max_dist_in_ref + 1;
+        for (; k < k1; ++k) {
+            if (!keep) continue;
+            const lzani_region& x = regs[k].r;
+            const int length = x.seq_end - x.seq_start;
+            line.clear();
+            line += g[q].name; line += '\t'; line += g[r].name; line += '\t';
+            line.append(num, real_to_chars(100.0 * x.num_matches / length, num, 6)); line += '\t';
+            auto put = [&](long v, char sep) { line += to_string(v); line += sep; };
+            put(length, '\t'); put(1 + x.seq_start, '\t'); put(x.seq_end, '\t');
+            if (x.ref_start < len1) { put(1 + x.ref_start, '\t'); put(x.ref_end, '\t'); }
+            else { put(rc_corr - (1 + x.ref_start), '\t'); put(rc_corr - x.ref_end, '\t'); }
+            put(x.num_matches, '\t'); put(x.num_mismatches, '\n');
+            o.write(line.data(), (streamsize)line.size());
+        }
+    }
+    return true;
+}
+
+static bool do_matching(const Engine& E, const vector<Genome>& g, const Filter& flt, ResultRows& results, vector<AlnRegion>* aln)
 {
     const uint32_t n = (uint32_t)g.size();
     if (P.verbosity >= 1) cerr << "All2all sparse" << endl;
@@ -253,8 +304,20 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, const Filter& 
             else { for (auto q : flt.rows[r]) query_ids.push_back(q); row_off.push_back(query_ids.size()); }
         }
         vector<lzani_result> out(row_off.back());
-        if (rc == LZANI_OK)
+        vector<lzani_region> regs;
+        if (rc == LZANI_OK && !aln)
             rc = E.run_rows(ctx, (uint32_t)ref_ids.size(), ref_ids.data(), row_off.data(), flt.empty() ? nullptr : query_ids.data(), out.data());
+        else if (rc == LZANI_OK) {
+            uint64_t cap = max<uint64_t>(1024, row_off.back() / 4), cnt = 0;
+            for (;;) {
+                regs.resize(cap);
+                rc = E.run_rows_regions(ctx, (uint32_t)ref_ids.size(), ref_ids.data(), row_off.data(), flt.empty() ? nullptr : query_ids.data(),
+                                        out.data(), regs.data(), cap, &cnt);
+                if (rc != LZANI_OK || cnt <= cap) break;
+                cap = cnt;
+            }
+            regs.resize(rc == LZANI_OK ? cnt : 0);
+        }
         if (rc != LZANI_OK) errs[d] = E.last_error(ctx);
         else {
             for (size_t k = 0; k < ref_ids.size(); ++k) {
@@ -267,6 +330,16 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, const Filter& 
                     row.push_back(IdResult{q, out[e]});
                 }
                 sort(row.begin(), row.end(), [](const IdResult& a, const IdResult& b) { return a.id < b.id; });
+            }
+            if (aln) {
+                static mutex mtx;
+                lock_guard<mutex> lck(mtx);
+                for (const auto& x : regs) {
+                    size_t k = upper_bound(row_off.begin(), row_off.end(), x.pair) - row_off.begin() - 1;
+                    uint32_t r = ref_ids[k], j = (uint32_t)(x.pair - row_off[k]);
+                    uint32_t q = flt.empty() ? j + (j >= r ? 1u : 0u) : query_ids[x.pair];
+                    aln->push_back(AlnRegion{r, q, x});
+                }
             }
             if (P.verbosity >= 2) {
                 lzani_timing t;
@@ -345,7 +418,9 @@ static bool run_all2all(const char* argv0)
     else {
         Engine E;
         if (!E.load(argv0)) return false;
-        if (!do_matching(E, g, flt, results)) return false;
+        vector<AlnRegion> aln;
+        if (!do_matching(E, g, flt, results, P.out_aln.empty() ? nullptr : &aln)) return false;
+        if (!P.out_aln.empty() && !store_alignment(g, aln)) return false;
     }
     stamp("LZ matching");
     if (!P.results_out.empty() && !write_raw(P.results_out, results)) return false;
@@ -374,7 +449,6 @@ int main(int argc, char** argv)
     if (!parse_params(argc, argv)) return 0;                  // the reference returns 0 here too (lz-ani.cpp:341-342)
     if (argc == 2) return 0;                                  // --version
     if (P.threads == 0) { P.threads = thread::hardware_concurrency(); if (!P.threads) P.threads = 1; }
-    if (!P.out_aln.empty()) { cerr << "--out-alignment is not available in the GPU build yet\n"; exit(1); }
     if (!run_all2all(argv[0])) { cerr << "Run failed" << endl; exit(1); }
     return 0;
 }

@@ -27,7 +27,7 @@ ERRORS = {-1: "LZANI_ERR_ARG", -2: "LZANI_ERR_PARAMS", -3: "LZANI_ERR_DEVICE",
 
 EXPORTS = ("lzani_default_params", "lzani_create", "lzani_destroy", "lzani_last_error",
            "lzani_set_genomes", "lzani_run_rows", "lzani_run_rows_device", "lzani_get_timing",
-           "lzani_debug_get_index")
+           "lzani_debug_get_index", "lzani_run_rows_regions")
 
 
 class LzaniError(RuntimeError):
@@ -70,6 +70,8 @@ def load_library():
         lib.lzani_run_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.lzani_run_rows_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.lzani_get_timing.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lzani_run_rows_regions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lzani_debug_get_index.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
         _lib = lib
     return _lib
@@ -146,6 +148,28 @@ class Engine:
         q = None if query_ids is None else np.ascontiguousarray(query_ids, dtype=np.uint32)
         self._check(self.lib.lzani_run_rows_device(self.h, len(ref_ids), _ptr(ref_ids), _ptr(row_off), _ptr(q),
                                                    C.c_void_p(int(d_out_ptr))), "lzani_run_rows_device")
+
+    REGION_DTYPE = np.dtype([("pair", np.uint64), ("ref_start", np.int32), ("ref_end", np.int32), ("seq_start", np.int32),
+                             ("seq_end", np.int32), ("num_matches", np.int32), ("num_mismatches", np.int32)])
+
+    def run_rows_regions(self, ref_ids, row_off, query_ids=None, capacity=1 << 16):
+        """(results int32[n_pairs, 3], regions structured array sorted by (pair, length desc, seq_start))."""
+        ref_ids = np.ascontiguousarray(ref_ids, dtype=np.uint32)
+        row_off = np.ascontiguousarray(row_off, dtype=np.uint64)
+        q = None if query_ids is None else np.ascontiguousarray(query_ids, dtype=np.uint32)
+        n_pairs = int(row_off[-1]) if len(row_off) else 0
+        while True:
+            out = np.zeros((n_pairs, 3), dtype=np.int32)
+            regs = np.zeros(capacity, dtype=self.REGION_DTYPE)
+            cnt = C.c_uint64(0)
+            self._check(self.lib.lzani_run_rows_regions(self.h, len(ref_ids), _ptr(ref_ids), _ptr(row_off), _ptr(q), _ptr(out),
+                                                        _ptr(regs), capacity, C.byref(cnt)), "lzani_run_rows_regions")
+            if cnt.value <= capacity:
+                break
+            capacity = int(cnt.value)
+        regs = regs[:cnt.value]
+        order = np.lexsort((regs["seq_start"], -(regs["seq_end"] - regs["seq_start"]), regs["pair"]))
+        return out, regs[order]
 
     def all2all(self):
         """int32[n, n, 3]: out[r, q] = parse(query=q, ref=r), diagonal zero."""

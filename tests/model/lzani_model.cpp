@@ -73,6 +73,8 @@ struct HostWave {
     TextView R, Q;
     IndexView I;
 
+    std::vector<RegionCoords>* regs = nullptr;
+    void emit_region(const RegionCoords& c) const { if (regs) regs->push_back(c); }
     void stamp(int) const {}
     u64 mism_fwd(int q0, int r0, int n) const
     {
@@ -141,6 +143,31 @@ int model_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t* len, 
             m.run(res);
             o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
         }
+    return 0;
+}
+
+// calc_regions through the streaming machine (ALN instantiation): regions of parse(query, ref) in
+// emission order, 6 ints each (ref_start, ref_end, seq_start, seq_end, num_matches, num_mismatches).
+int model_pair_regions(const uint8_t* ref, uint32_t ref_len, const uint8_t* qry, uint32_t qry_len, const int32_t* p8,
+                       int32_t* res, int32_t* regions, uint32_t max_regions, uint32_t* n_regions)
+{
+    Params P{p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]};
+    if (!params_supported(P)) return -1;
+    IndexGeom geo = index_geometry(ref_text_len((int)std::max(ref_len, qry_len), P.mrd), P.mal);
+    Genome R, Q;
+    pack_genome(R, ref, (int)ref_len, P); build_index(R, P, geo);
+    pack_genome(Q, qry, (int)qry_len, P);
+    std::vector<RegionCoords> regs;
+    HostWave w{P, R.rview(), Q.qview(), R.iv};
+    w.regs = &regs;
+    PairMachine<HostWave, true> m(w, P, R.T, Q.D);
+    m.run(res);
+    *n_regions = (uint32_t)regs.size();
+    for (uint32_t k = 0; k < regs.size() && k < max_regions; ++k) {
+        int32_t* o = regions + 6 * k;
+        o[0] = regs[k].ref_start; o[1] = regs[k].ref_end; o[2] = regs[k].seq_start; o[3] = regs[k].seq_end;
+        o[4] = regs[k].nm; o[5] = regs[k].nmm;
+    }
     return 0;
 }
 

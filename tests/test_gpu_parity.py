@@ -222,3 +222,31 @@ def test_filtered_heavy_tailed_rows_config5_shape():
         for x in rows[r]:
             assert tuple(got[e]) == O.oracle_pair(seqs[r], seqs[x]), (r, x)
             e += 1
+
+
+def test_regions_through_c_abi():
+    """lzani_run_rows_regions (the --out-alignment path): every region of every example pair equals
+    the oracle's calc_regions; the results_t triples are unchanged by the alignment instantiation."""
+    _, ex = U.load_example()
+    eng = L.Engine()
+    eng.set_genomes(ex)
+    n = len(ex)
+    ref_ids, row_off = L.dense_rows(n)
+    out, regs = eng.run_rows_regions(ref_ids, row_off, None, capacity=64)      # forces the grow-and-retry path
+    plain = eng.run_rows(ref_ids, row_off, None)
+    eng.close()
+    assert np.array_equal(out, plain)
+    e = 0
+    total = 0
+    for r in range(n):
+        for q in range(n):
+            if q == r:
+                continue
+            mine = regs[regs["pair"] == e]
+            _, want = O.oracle_pair(ex[r], ex[q], None, want_regions=True)
+            cols = ("ref_start", "ref_end", "seq_start", "seq_end", "num_matches", "num_mismatches")
+            got = np.stack([mine[k] for k in cols], axis=1) if len(mine) else np.zeros((0, 6), np.int32)
+            assert np.array_equal(got, want), (r, q)
+            total += len(want)
+            e += 1
+    assert total == len(regs) and total > 100

@@ -156,3 +156,11 @@ def test_end_to_end_on_gpu(tmp_path):
     want = U.emit_tsv(names, [len(s) for s in seqs], O.oracle_all2all(seqs, dict(mal=15, msl=9, reg=60), threads=8), U.STANDARD)
     assert p.returncode == 0 and open(out).read() == want
     assert run(["all2all", "--in-fasta", fa, "-o", out, "--mqd", "100"]).returncode == 1      # outside the envelope: clean failure
+    # --out-alignment: example/output/ani.aln.tsv as a multiset of rows (the reference's row order is thread-dependent)
+    aln = str(tmp_path / "ani.aln.tsv")
+    p = run(["all2all", "--in-fasta", fa, "-o", out, "--out-alignment", aln])
+    assert p.returncode == 0, p.stderr
+    got = open(aln).read().split("\n")
+    gold = open(os.path.join(U.GOLD, "example", "ani.aln.tsv")).read().split("\n")
+    assert got[0] == gold[0] and sorted(got[1:]) == sorted(gold[1:])
+    assert open(out).read() == open(os.path.join(U.GOLD, "example", "ani.tsv")).read()

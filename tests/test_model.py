@@ -44,3 +44,23 @@ def test_model_rejects_unsupported_params():
         U.model_all2all(U.edge_set()[:2], dict(mqd=65))
     with pytest.raises(ValueError):
         U.model_all2all(U.edge_set()[:2], dict(aw=65))
+
+
+def test_model_regions_stream_equals_calc_regions():
+    """The alignment instantiation (RegionCoords fed with the factor stream, including the data_pos
+    quirk of the gap fill) against the oracle's calc_regions, itself pinned by example/output/ani.aln.tsv."""
+    _, ex = U.load_example()
+    cases = [(r, q, None) for r in range(0, 12, 2) for q in range(12) if r != q]
+    cases += [(r, q, dict(mal=15, msl=9, reg=60)) for r in (1, 5) for q in (0, 4, 6)]
+    cases += [(r, q, dict(mrd=20, mqd=60)) for r in (3,) for q in (0, 1, 2)]
+    for r, q, prm in cases:
+        res, regs = U.model_pair_regions(ex[r], ex[q], prm)
+        ores, oregs = O.oracle_pair(ex[r], ex[q], prm, want_regions=True)
+        assert res == ores and np.array_equal(regs, oregs), (r, q, prm)
+    E = U.edge_set()
+    for r in range(len(E)):
+        for q in range(len(E)):
+            if r != q:
+                res, regs = U.model_pair_regions(E[r], E[q])
+                ores, oregs = O.oracle_pair(E[r], E[q], None, want_regions=True)
+                assert res == ores and np.array_equal(regs, oregs), (r, q)

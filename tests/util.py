@@ -166,3 +166,20 @@ def model_all2all(seqs, params=None):
     if rc != 0:
         raise ValueError("model: unsupported parameters")
     return out
+
+
+def model_pair_regions(ref, qry, params=None):
+    """(result triple, regions sorted like calc_regions) through the ALN instantiation of the model."""
+    lib = model_lib()
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    res = np.zeros(3, dtype=np.int32)
+    regs = np.zeros((1 << 14, 6), dtype=np.int32)
+    n = C.c_uint32(0)
+    rc = lib.model_pair_regions(O._ptr(ref), len(ref), O._ptr(qry), len(qry), O.params_array(params), O._ptr(res),
+                                O._ptr(regs), 1 << 14, C.byref(n))
+    if rc != 0:
+        raise ValueError("model: unsupported parameters")
+    g = regs[:n.value]
+    order = sorted(range(len(g)), key=lambda k: (-(int(g[k][3]) - int(g[k][2])), int(g[k][2])))
+    return tuple(int(x) for x in res), g[order]
