@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--genomes", type=int, default=0, help="0 = 1000*sqrt(gpus)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--lmin", type=int, default=36000, help="ancestor length range of the synthetic set")
+    ap.add_argument("--lmax", type=int, default=44000)
+    ap.add_argument("--params", default="", help="LZ parameter overrides, e.g. mal=15,msl=9,reg=60 (BASELINE configs[3])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU rehearsals)")
     ap.add_argument("--device", type=int, default=-1, help="force the HIP device ordinal (rehearsals: all ranks on GPU 0)")
     args = ap.parse_args()
@@ -137,14 +140,15 @@ def main():
             dist.init_process_group(backend=args.backend)
 
     n = args.genomes or int(round(1000 * math.sqrt(max(world, 1))))
-    names, seqs = SG.make_set(n, args.seed)
+    over = {k: int(v) for k, v in (kv.split("=") for kv in args.params.split(",") if kv)}
+    names, seqs = SG.make_set(n, args.seed, lmin=args.lmin, lmax=args.lmax)
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
     # reference order: length-descending, then name (CSeqReservoir::reorder_items, seq_reservoir.cpp:215-251)
     order = sorted(range(n), key=lambda i: (-int(lens[i]), names[i]))
     seqs = [seqs[i] for i in order]
     lens = lens[order]
 
-    eng = L.Engine(None, device=dev)
+    eng = L.Engine(over or None, device=dev)
     params = eng.params
     eng.set_genomes(seqs)                      # untimed: genomes resident in HBM before the timed region
 
@@ -200,8 +204,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (2-bit packed symbols, 64-bit lane masks; f64 only in the anchor/seed arbitration)",
             "data": "synthetic",
-            "config": {"workload": f"{n} synthetic ~40 kbp viral genomes (families of 10, 1-15% divergence, seed {args.seed}), "
-                                   f"dense all2all, default LZ params, {total_pairs} directed pairs/step",
+            "config": {"workload": f"{n} synthetic genomes of {args.lmin}-{args.lmax} bp (families of 10, 1-15% divergence, seed {args.seed}), "
+                                   f"dense all2all, {'default LZ params' if not over else 'LZ params ' + args.params}, {total_pairs} directed pairs/step",
                        "genomes": n, "pairs_per_step": total_pairs, "pairs_per_gpu": my_pairs,
                        "sharding": "reference rows cyclic over ranks, genomes replicated, one RCCL all_gather of int32[3] per pair"
                                    if world > 1 else "single GPU, all rows",
