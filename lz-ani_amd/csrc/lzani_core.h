@@ -66,8 +66,8 @@ LZ_HD TextView qry_view(const u64* t2, const u64* nm, int L, int mrd, bool nfree
 { return TextView{t2, nm, L + mrd, L, -1, nfree}; }
 
 // N-free texts: is p a real symbol / where does the run of real symbols containing p end
-LZ_HD bool pos_valid(const TextView& t, int p)
-{ return p >= 0 && (p < t.L || (t.rc0 >= 0 && p >= t.rc0 && p < t.rc0 + t.L)); }
+LZ_HD bool pos_valid(const TextView& t, int p)      // branch-free: unsigned range tests, bitwise combination
+{ return ((u32)p < (u32)t.L) | ((t.rc0 >= 0) & ((u32)(p - t.rc0) < (u32)t.L)); }
 LZ_HD int run_end(const TextView& t, int p)
 { return p < t.L ? t.L : ((t.rc0 >= 0 && p >= t.rc0 && p < t.rc0 + t.L) ? t.rc0 + t.L : p); }
 
@@ -134,8 +134,13 @@ LZ_HD int isN_at(const TextView& t, int p) { return (int)((t.nm[p >> 6] >> (p & 
 // anything (reference: code_N_ref = 4 vs code_N_seq = 5, defs.h:28-30).
 LZ_HD int sym_match(const TextView& R, int rp, const TextView& Q, int qp)
 {
-    if (R.nfree && Q.nfree)
-        return pos_valid(R, rp) && pos_valid(Q, qp) && sym_at(R, rp) == sym_at(Q, qp);
+    if (R.nfree && Q.nfree) {
+        // both loads are issued unconditionally (from position 0 when the position is not a symbol), so the
+        // lane code has no branch: divergent branches cost scalar exec-mask bookkeeping on every wave
+        const bool vr = pos_valid(R, rp), vq = pos_valid(Q, qp);
+        const int a = sym_at(R, vr ? rp : 0), b = sym_at(Q, vq ? qp : 0);
+        return (int)(vr & vq & (a == b));
+    }
     if (rp < 0 || rp >= R.len || qp < 0 || qp >= Q.len) return 0;
     if (isN_at(R, rp) | isN_at(Q, qp)) return 0;
     return sym_at(R, rp) == sym_at(Q, qp);

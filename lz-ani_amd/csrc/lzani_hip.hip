@@ -370,13 +370,18 @@ struct DevWave {
         if (!FAST || W > 128 || I.tagmask != (u32)lowmask(tb))          // the stored tag must identify the k-mer
             return find_event_generic(i, n, trk, r_end, lit, ev_lane, bpos, blen);
 
-        // every independent load of the round first
-        u32 hq = KM_INVALID, rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
-        if (lane < n) hq = qkL[i + lane];
-        if (W > 0) {
-            if (lane < nt) qk = qkS[i + lane];
-            if (lane < W) rk0 = rkS[r_end + lane];
-            if (lane + 64 < W) rk1 = rkS[r_end + 64 + lane];
+        // every independent load of the round first, unconditionally (the k-mer arrays are padded by two
+        // 64-entry blocks, so the addresses are always in bounds) and masked afterwards: no branches
+        u32 hq = qkL[i + lane], rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
+        hq = lane < n ? hq : KM_INVALID;
+        if (W > 0) {                                                 // wave-uniform
+            const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
+            qk = qkS[i + lane];
+            rk0 = rkS[r_end + w0];
+            rk1 = rkS[r_end + w1];
+            qk = lane < nt ? qk : KM_INVALID;
+            rk0 = lane < W ? rk0 : KM_INVALID;
+            rk1 = lane + 64 < W ? rk1 : KM_INVALID;
         }
         // anchor candidates: first bucket entry with this step's tag, and how many follow.  Buckets
         // hold ~0.6 entries: the first four are fetched at once (clamped indices, one wait), a loop
@@ -724,7 +729,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, c->dev));
-    const u32 max_blocks = (u32)prop.multiProcessorCount * 8u;
+    u32 blocks_per_cu = 8;                                   // 8 blocks x 4 waves = 8 waves per SIMD
+    if (const char* e = getenv("LZANI_BLOCKS_PER_CU")) blocks_per_cu = (u32)std::max(1, std::min(8, atoi(e)));   // occupancy experiments
+    const u32 max_blocks = (u32)prop.multiProcessorCount * blocks_per_cu;
 
     for (u32 k0 = 0; k0 < n_rows; k0 += c->slots) {
         u32 rows = std::min(c->slots, n_rows - k0);
