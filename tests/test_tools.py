@@ -1,0 +1,41 @@
+"""CPU: the seeded workload generator is byte-stable, and bench.py's byte accounting is SURVEY 8(d)'s."""
+import hashlib
+import importlib.util
+import os
+
+import numpy as np
+
+import shard as SH
+import synth_genomes as SG
+import util as U
+
+
+def test_generator_is_byte_stable():
+    names, seqs = SG.make_set(12, 1)
+    assert names[0] == "g000000_f0_m0" and names[11] == "g000011_f1_m1"
+    assert [len(s) for s in seqs[:4]] == [40307, 40278, 40461, 40500]
+    h = hashlib.sha256(b"".join(s.tobytes() for s in seqs)).hexdigest()
+    assert h == hashlib.sha256(b"".join(s.tobytes() for s in SG.make_set(12, 1)[1])).hexdigest()
+    assert h != hashlib.sha256(b"".join(s.tobytes() for s in SG.make_set(12, 2)[1])).hexdigest()
+    assert all(s.dtype == np.uint8 and s.max() <= 3 for s in seqs)
+    # member 0 of a family is the ancestor, members differ from it by substitutions and indels
+    same = (seqs[0][:100] == seqs[1][:100]).mean()          # before the first indel shifts the frame
+    assert 0.7 < same <= 1.0 and not np.array_equal(seqs[0], seqs[1])
+
+
+def test_splitmix_reference_values():
+    # splitmix64 with seed 0: first outputs of the published sequence
+    v = SG.splitmix64(0, np.arange(3, dtype=np.uint64))
+    assert [int(x) for x in v] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+def test_bench_algorithmic_bytes_formula():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(U.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prm = dict(mal=11, msl=7, mrd=40, mqd=40, reg=35, aw=15, am=7, ar=3)
+    lens = np.array([40000, 40000], dtype=np.int64)
+    # 10,000 + 20,030 + 160,120 + 12 = 190,162 B per directed pair at Lq = Lr = 40,000
+    assert bench.algorithmic_bytes(lens, [0], prm) == 190162
+    assert bench.algorithmic_bytes(lens, [0, 1], prm) == 2 * 190162
+    assert bench.host_cores() >= 1
