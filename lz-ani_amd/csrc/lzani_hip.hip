@@ -611,6 +611,18 @@ bool trace_on()
 }
 #define TRACE(...) do { if (trace_on()) { fprintf(stderr, "[lzani] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
+// Temporary device buffer, released on every exit path of the call that owns it.
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)); }
+    operator T*() const { return p; }
+};
+
 int fail(lzani_ctx* c, int code, const std::string& msg)
 {
     if (c) c->err = msg;
@@ -715,15 +727,16 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     int rc = ensure_slabs(c, n_rows);
     if (rc) return rc;
 
-    u32* d_ref = nullptr; u64* d_off = nullptr; u32* d_q = nullptr; u32* d_qorder = nullptr; u64* d_qcum = nullptr;
-    HIPCHK(c, hipMalloc(&d_qorder, (size_t)n_rows * 4));
-    HIPCHK(c, hipMalloc(&d_qcum, (size_t)(n_rows + 1) * 8));
-    HIPCHK(c, hipMalloc(&d_ref, (size_t)n_rows * 4));
-    HIPCHK(c, hipMalloc(&d_off, (size_t)(n_rows + 1) * 8));
+    DevBuf<u32> d_ref, d_q, d_qorder;
+    DevBuf<u64> d_off, d_qcum;
+    HIPCHK(c, d_qorder.alloc(n_rows));
+    HIPCHK(c, d_qcum.alloc((size_t)n_rows + 1));
+    HIPCHK(c, d_ref.alloc(n_rows));
+    HIPCHK(c, d_off.alloc((size_t)n_rows + 1));
     HIPCHK(c, hipMemcpyAsync(d_ref, ref_ids, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_off, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
     if (query_ids) {
-        HIPCHK(c, hipMalloc(&d_q, (size_t)n_pairs * 4));
+        HIPCHK(c, d_q.alloc(n_pairs));
         HIPCHK(c, hipMemcpyAsync(d_q, query_ids, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     }
 
@@ -824,7 +837,6 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         }
         c->tm.pairs += e1 - e0;
     }
-    hipFree(d_ref); hipFree(d_off); hipFree(d_q); hipFree(d_qorder); hipFree(d_qcum);
     return LZANI_OK;
 }
 
@@ -899,9 +911,10 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
     c->dir_stride = ((u64)1 << c->geo.dirbits) + 1;
     c->ent_stride = (u64)c->Tmax;
 
-    uint8_t* d_codes = nullptr; u64* d_codeoff = nullptr;
-    HIPCHK(c, hipMalloc(&d_codes, std::max<u64>(total_codes, 1)));
-    HIPCHK(c, hipMalloc(&d_codeoff, (size_t)n * 8));
+    DevBuf<uint8_t> d_codes;
+    DevBuf<u64> d_codeoff;
+    HIPCHK(c, d_codes.alloc(total_codes));
+    HIPCHK(c, d_codeoff.alloc(n));
     HIPCHK(c, hipMalloc(&c->d_t2, total_nm * 16));
     HIPCHK(c, hipMalloc(&c->d_nm, total_nm * 8));
     HIPCHK(c, hipMalloc(&c->d_nmoff, (size_t)n * 8));
@@ -924,7 +937,7 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
             stage.resize(bytes);
             u64 o = 0;
             for (u32 k = g; k < g1; ++k) { if (len[k]) memcpy(stage.data() + o, codes[k], len[k]); o += len[k]; }
-            if (bytes) HIPCHK(c, hipMemcpy(d_codes + codeoff[g], stage.data(), bytes, hipMemcpyHostToDevice));
+            if (bytes) HIPCHK(c, hipMemcpy(d_codes.p + codeoff[g], stage.data(), bytes, hipMemcpyHostToDevice));
             g = g1;
         }
     }
@@ -937,7 +950,7 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
     for (u32 g0 = 0; g0 < n; g0 += 32768) {
         u32 cnt = std::min<u32>(32768, n - g0);
         hipLaunchKernelGGL(k_pack, dim3((u32)((maxblk + 127) / 128), cnt), dim3(128), 0, c->stream,
-                           d_codes, d_codeoff + g0, c->d_t2, c->d_nm, c->d_nmoff + g0, c->d_L + g0, c->d_hasN + g0, c->P.mrd, cnt);
+                           d_codes.p, d_codeoff.p + g0, c->d_t2, c->d_nm, c->d_nmoff + g0, c->d_L + g0, c->d_hasN + g0, c->P.mrd, cnt);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -947,7 +960,6 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
         c->all_nfree = std::all_of(hn.begin(), hn.end(), [](int v) { return v == 0; });
     }
     TRACE("set_genomes: n=%u Tmax=%d dirbits=%d posbits=%d tagmask=%x", n, c->Tmax, c->geo.dirbits, c->geo.posbits, c->geo.tagmask);
-    hipFree(d_codes); hipFree(d_codeoff);
     return LZANI_OK;
 }
 
@@ -968,14 +980,13 @@ int lzani_run_rows(lzani_ctx* c, uint32_t n_rows, const uint32_t* ref_ids, const
     const u64 n_pairs = n_rows ? row_off[n_rows] : 0;
     if (n_pairs && !out) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: null output");
     HIPCHK(c, hipSetDevice(c->dev));
-    int* d_out = nullptr;
-    if (n_pairs) HIPCHK(c, hipMalloc(&d_out, n_pairs * sizeof(lzani_result)));
-    int rc = run_rows_impl(c, n_rows, ref_ids, row_off, query_ids, d_out);
+    DevBuf<lzani_result> d_out;
+    if (n_pairs) HIPCHK(c, d_out.alloc(n_pairs));
+    int rc = run_rows_impl(c, n_rows, ref_ids, row_off, query_ids, (int*)d_out.p);
     if (rc == LZANI_OK && n_pairs) {
-        hipError_t e = hipMemcpy(out, d_out, n_pairs * sizeof(lzani_result), hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(out, d_out.p, n_pairs * sizeof(lzani_result), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(c, LZANI_ERR_DEVICE, std::string("copy results: ") + hipGetErrorString(e));
     }
-    hipFree(d_out);
     return rc;
 }
 
@@ -990,23 +1001,24 @@ int lzani_run_rows_regions(lzani_ctx* c, uint32_t n_rows, const uint32_t* ref_id
     if (n_pairs && !out) return fail(c, LZANI_ERR_ARG, "lzani_run_rows_regions: null output");
     *n_regions = 0;
     HIPCHK(c, hipSetDevice(c->dev));
-    int* d_out = nullptr;
-    RegionSink rs{nullptr, nullptr, capacity};
-    if (n_pairs) HIPCHK(c, hipMalloc(&d_out, n_pairs * sizeof(lzani_result)));
-    HIPCHK(c, hipMalloc(&rs.d_regions, std::max<uint64_t>(capacity, 1) * sizeof(lzani_region)));
-    HIPCHK(c, hipMalloc(&rs.d_count, sizeof(unsigned long long)));
-    HIPCHK(c, hipMemset(rs.d_count, 0, sizeof(unsigned long long)));
-    int rc = run_rows_impl(c, n_rows, ref_ids, row_off, query_ids, d_out, &rs);
+    DevBuf<lzani_result> d_out;
+    DevBuf<lzani_region> d_regions;
+    DevBuf<unsigned long long> d_count;
+    if (n_pairs) HIPCHK(c, d_out.alloc(n_pairs));
+    HIPCHK(c, d_regions.alloc(capacity));
+    HIPCHK(c, d_count.alloc(1));
+    HIPCHK(c, hipMemset(d_count.p, 0, sizeof(unsigned long long)));
+    RegionSink rs{d_regions.p, d_count.p, capacity};
+    int rc = run_rows_impl(c, n_rows, ref_ids, row_off, query_ids, (int*)d_out.p, &rs);
     if (rc == LZANI_OK) {
         unsigned long long cnt = 0;
         hipError_t e = hipMemcpy(&cnt, rs.d_count, sizeof cnt, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && n_pairs) e = hipMemcpy(out, d_out, n_pairs * sizeof(lzani_result), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_pairs) e = hipMemcpy(out, d_out.p, n_pairs * sizeof(lzani_result), hipMemcpyDeviceToHost);
         if (e == hipSuccess && cnt && capacity)
             e = hipMemcpy(regions, rs.d_regions, std::min<uint64_t>(cnt, capacity) * sizeof(lzani_region), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(c, LZANI_ERR_DEVICE, std::string("copy regions: ") + hipGetErrorString(e));
         *n_regions = cnt;
     }
-    hipFree(d_out); hipFree(rs.d_regions); hipFree(rs.d_count);
     return rc;
 }
 
@@ -1025,13 +1037,12 @@ int lzani_debug_get_index(lzani_ctx* c, uint32_t id, uint64_t* t2, uint64_t* nm,
     HIPCHK(c, hipSetDevice(c->dev));
     int rc = ensure_slabs(c, 1);
     if (rc) return rc;
-    u32* d_ref = nullptr;
-    HIPCHK(c, hipMalloc(&d_ref, 4));
-    HIPCHK(c, hipMemcpy(d_ref, &id, 4, hipMemcpyHostToDevice));
+    DevBuf<u32> d_ref;
+    HIPCHK(c, d_ref.alloc(1));
+    HIPCHK(c, hipMemcpy(d_ref.p, &id, 4, hipMemcpyHostToDevice));
     rc = build_indexes(c, d_ref, 1);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(d_ref);
     int T = ref_text_len(c->L[id], c->P.mrd);
     size_t wn = text_wordsN(T);
     if (nm) HIPCHK(c, hipMemcpy(nm, c->d_nm + c->nmoff[id], wn * 8, hipMemcpyDeviceToHost));
