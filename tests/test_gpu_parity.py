@@ -250,3 +250,23 @@ def test_regions_through_c_abi():
             total += len(want)
             e += 1
     assert total == len(regs) and total > 100
+
+
+def test_mixed_n_content_and_parameter_instantiations():
+    """All kernel instantiations against the oracle on one set: genomes with and without N runs (NFREE
+    on/off), default and non-default parameters (DEFP on/off), k-mer words on/off (mal 16 > 15)."""
+    st = SG.Stream(77)
+    _, seqs = SG.make_set(36, 9, lmin=5000, lmax=9000, fam=6)
+    clean = [s.copy() for s in seqs]
+    for k in range(0, 36, 3):                                  # a third of the genomes get N runs / IUPAC codes
+        s = seqs[k].copy()
+        for _ in range(st.randint(1, 4)):
+            a = st.randint(0, len(s) - 60)
+            s[a:a + st.randint(1, 50)] = 5
+        seqs[k] = s
+    for name, data in (("with N", seqs), ("N-free", clean)):
+        for prm in (None, dict(reg=30), dict(mal=13, msl=8, mrd=30, mqd=50, aw=20, am=9, ar=2), dict(mal=16, msl=7)):
+            got = gpu_all2all(data, prm)
+            want = O.oracle_all2all(data, prm, threads=16)
+            bad = np.argwhere((got != want).any(axis=2))
+            assert len(bad) == 0, (name, prm, bad[:3].tolist())
