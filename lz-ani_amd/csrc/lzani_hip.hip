@@ -106,8 +106,9 @@ struct IdxArgs {
     u32* dirz;               // slots * dir_stride
     u32* ent;                // slots * ent_stride
     u64 dir_stride, ent_stride;
-    int mal, mrd;
+    int mal, mrd;            // mal = the k of this index (min_anchor_len, or min_seed_len for the seed index)
     IndexGeom geo;
+    int seed;                // 1: index of the msl-mers (key words from kmS, mixed here)
 };
 
 __device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, u32& bucket, u32& entry)
@@ -118,9 +119,9 @@ __device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, 
     u64 o = a.G.nmoff[g];
     u64 h;
     if (a.G.kmL) {
-        u32 v = a.G.kmL[64 * o + p];
+        u32 v = a.seed ? a.G.kmS[64 * o + p] : a.G.kmL[64 * o + p];
         if (v == KM_INVALID) return false;
-        h = v;
+        h = a.seed ? mix_key(v, a.geo.kb) : (u64)v;
     } else {
         TextView R = ref_view(a.G.t2 + 2 * o, a.G.nm + o, a.G.L[g], a.mrd, false);
         u64 key;
@@ -562,6 +563,67 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_pairs_tpp: thread-per-pair variant.  Every lane owns one directed pair and runs the same pair
+// machine with the lane-serial policy (LaneWave, lzani_core.h): 64 independent pairs per wavefront,
+// no cross-lane traffic, the close seeds come from a second (msl) index of the reference.  Lanes pull
+// their pairs from the per-XCD queues one ticket each, so a finished lane never waits for its wave.
+// ------------------------------------------------------------------------------------------
+struct TppArgs {
+    PairArgs pa;
+    const u32* sdirz;        // seed index slabs, like dirz/ent
+    const u32* sent;
+    u64 sdir_stride, sent_stride;
+    IndexGeom sgeo;
+};
+
+template <bool NFREE, bool DEFP>
+__global__ void __launch_bounds__(256) k_pairs_tpp(TppArgs ta)
+{
+    const PairArgs& a = ta.pa;
+    const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
+    u32 qx = xcc_id() % NQUEUES, dry = 0;
+    for (;;) {
+        const unsigned long long t = atomicAdd(&a.cursor[qx], 1ULL);     // one ticket per lane
+        const u32 rb = a.qb[qx], re = a.qb[qx + 1];
+        const u64 tk = a.qcum[rb] + t;
+        if (tk >= a.qcum[re]) {
+            if (++dry >= NQUEUES) break;
+            qx = (qx + 1) % NQUEUES;
+            continue;
+        }
+        u32 lo = rb, hi = re;
+        while (hi - lo > 1) {
+            u32 mid = (lo + hi) >> 1;
+            if (a.qcum[mid] <= tk) lo = mid; else hi = mid;
+        }
+        const u32 slot = a.qorder[lo];
+        const u32 r = a.ref_ids[slot];
+        const u32 j = (u32)(tk - a.qcum[lo]);
+        const u64 e = a.row_off[slot] + j;
+        const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
+        const int Lr = a.G.L[r], Lq = a.G.L[q];
+        const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
+        const int T = ref_text_len(Lr, Pk.mrd), D = Lq + Pk.mrd;
+        IndexView iv, sv;
+        iv.dirz = a.dirz + slot * a.dir_stride;
+        iv.ent = a.ent + slot * a.ent_stride;
+        iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
+        sv.dirz = ta.sdirz + slot * ta.sdir_stride;
+        sv.ent = ta.sent + slot * ta.sent_stride;
+        sv.kb = ta.sgeo.kb; sv.dirbits = ta.sgeo.dirbits; sv.posbits = ta.sgeo.posbits; sv.tagmask = ta.sgeo.tagmask;
+        const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
+        LaneWave w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
+                   qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, sv,
+                   a.G.kmL + 64 * qo, a.G.kmS + 64 * qo};
+        PairMachine<LaneWave> m(w, Pk, T, D);
+        int res[3];
+        m.run(res);
+        int* o = a.out + 3 * e;
+        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+    }
+}
+
 }  // namespace lzani
 
 // ============================================================================================
@@ -594,6 +656,11 @@ struct lzani_ctx {
 
     u32* d_dirz = nullptr;
     u32* d_ent = nullptr;
+    u32* d_sdirz = nullptr;       // seed (msl) index slabs, thread-per-pair kernel only
+    u32* d_sent = nullptr;
+    u64 sdir_stride = 0;
+    IndexGeom sgeo{};
+    bool use_tpp = false;
     u32 slots = 0;
     u64 dir_stride = 0, ent_stride = 0;
     unsigned long long* d_cursor = nullptr;
@@ -646,13 +713,20 @@ void free_genomes(lzani_ctx* c)
 }
 void free_slabs(lzani_ctx* c)
 {
-    hipFree(c->d_dirz); hipFree(c->d_ent);
-    c->d_dirz = c->d_ent = nullptr; c->slots = 0;
+    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_sdirz); hipFree(c->d_sent);
+    c->d_dirz = c->d_ent = c->d_sdirz = c->d_sent = nullptr; c->slots = 0;
 }
 
 int ensure_slabs(lzani_ctx* c, u32 want_rows)
 {
-    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride);
+    {   // thread-per-pair kernel: diagnostic opt-in (LZANI_KERNEL=tpp); needs the k-mer words and exact seed tags
+        const char* e = getenv("LZANI_KERNEL");
+        c->sgeo = index_geometry(c->Tmax, c->P.msl);
+        c->sdir_stride = ((u64)1 << c->sgeo.dirbits) + 1;
+        c->use_tpp = e && !strcmp(e, "tpp") && c->d_kmL &&
+                     c->sgeo.tagmask == (u32)lowmask(c->sgeo.kb - c->sgeo.dirbits);
+    }
+    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + (c->use_tpp ? c->sdir_stride + c->ent_stride : 0));
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     size_t have = c->slots * per_slot;
@@ -662,6 +736,10 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     free_slabs(c);
     HIPCHK(c, hipMalloc(&c->d_dirz, (size_t)slots * c->dir_stride * 4));
     HIPCHK(c, hipMalloc(&c->d_ent, (size_t)slots * c->ent_stride * 4));
+    if (c->use_tpp) {
+        HIPCHK(c, hipMalloc(&c->d_sdirz, (size_t)slots * c->sdir_stride * 4));
+        HIPCHK(c, hipMalloc(&c->d_sent, (size_t)slots * c->ent_stride * 4));
+    }
     c->slots = slots;
     return LZANI_OK;
 }
@@ -676,7 +754,7 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
     ia.ref_ids = d_ref_ids;
     ia.dirz = c->d_dirz; ia.ent = c->d_ent;
     ia.dir_stride = c->dir_stride; ia.ent_stride = c->ent_stride;
-    ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo;
+    ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo; ia.seed = 0;
     const u32 nb = 1u << c->geo.dirbits;
     if (c->d_kmL && !c->kmers_ready) {            // per-genome k-mer words, inside the timed index stage
         for (u32 g0 = 0; g0 < c->n; g0 += 32768) {
@@ -696,6 +774,19 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
     hipLaunchKernelGGL(k_idx_fill, gp, dim3(256), 0, c->stream, ia, c->Tmax);
     hipLaunchKernelGGL(k_idx_sort, dim3((nb + 255) / 256, rows), dim3(256), 0, c->stream,
                        c->d_dirz, c->d_ent, c->dir_stride, c->ent_stride, nb);
+    if (c->use_tpp) {                             // second index over the msl-mers
+        IdxArgs sa = ia;
+        sa.dirz = c->d_sdirz; sa.ent = c->d_sent; sa.dir_stride = c->sdir_stride;
+        sa.mal = c->P.msl; sa.geo = c->sgeo; sa.seed = 1;
+        const u32 snb = 1u << c->sgeo.dirbits;
+        HIPCHK(c, hipMemsetAsync(c->d_sdirz, 0, (size_t)rows * c->sdir_stride * 4, c->stream));
+        hipLaunchKernelGGL(k_idx_count, gp, dim3(256), 0, c->stream, sa, c->Tmax);
+        hipLaunchKernelGGL(k_idx_scan, dim3(rows), dim3(1024), 0, c->stream, c->d_sdirz, c->sdir_stride, snb);
+        hipLaunchKernelGGL(k_idx_fill, gp, dim3(256), 0, c->stream, sa, c->Tmax);
+        hipLaunchKernelGGL(k_idx_sort, dim3((snb + 255) / 256, rows), dim3(256), 0, c->stream,
+                           c->d_sdirz, c->d_sent, c->sdir_stride, c->ent_stride, snb);
+        c->tm.index_launches += 4;
+    }
     HIPCHK(c, hipGetLastError());
     c->tm.index_launches += 4;
     return LZANI_OK;
@@ -793,7 +884,17 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             const bool defp = q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3;
             const dim3 gd(blocks), bd(256);
             pa.reg_out = rs ? rs->d_regions : nullptr; pa.reg_count = rs ? rs->d_count : nullptr; pa.reg_cap = rs ? rs->capacity : 0;
-            if (rs && c->d_kmL) hipLaunchKernelGGL((k_pairs<true, false, false, true>), gd, bd, 0, c->stream, pa);
+            if (c->use_tpp && !rs) {
+                TppArgs ta;
+                ta.pa = pa; ta.sdirz = c->d_sdirz; ta.sent = c->d_sent;
+                ta.sdir_stride = c->sdir_stride; ta.sent_stride = c->ent_stride; ta.sgeo = c->sgeo;
+                const u64 lanes = e1 - e0;
+                const dim3 tg((u32)std::min<u64>((lanes + 255) / 256, max_blocks));
+                if (c->all_nfree && defp) hipLaunchKernelGGL((k_pairs_tpp<true, true>), tg, bd, 0, c->stream, ta);
+                else if (c->all_nfree) hipLaunchKernelGGL((k_pairs_tpp<true, false>), tg, bd, 0, c->stream, ta);
+                else if (defp) hipLaunchKernelGGL((k_pairs_tpp<false, true>), tg, bd, 0, c->stream, ta);
+                else hipLaunchKernelGGL((k_pairs_tpp<false, false>), tg, bd, 0, c->stream, ta);
+            } else if (rs && c->d_kmL) hipLaunchKernelGGL((k_pairs<true, false, false, true>), gd, bd, 0, c->stream, pa);
             else if (rs) hipLaunchKernelGGL((k_pairs<false, false, false, true>), gd, bd, 0, c->stream, pa);
             else if (!c->d_kmL) hipLaunchKernelGGL((k_pairs<false, false, false>), gd, bd, 0, c->stream, pa);
             else if (c->all_nfree && defp) hipLaunchKernelGGL((k_pairs<true, true, true>), gd, bd, 0, c->stream, pa);

@@ -20,8 +20,8 @@ namespace {
 struct Genome {
     int L, T, D;
     std::vector<u64> t2, nm;
-    std::vector<u32> dirz, ent;
-    IndexView iv;
+    std::vector<u32> dirz, ent, sdirz, sent, kmL, kmS;
+    IndexView iv, sv;
     int mrd;
     bool nfree;
     TextView rview() const { return ref_view(t2.data(), nm.data(), L, mrd, nfree); }
@@ -47,25 +47,43 @@ void pack_genome(Genome& g, const uint8_t* codes, int L, const Params& P)
     for (int j = 0; j < L; ++j) { int c = codes[L - 1 - j]; put(rc0 + j, c < 4 ? 3 - c : 4); }
 }
 
-void build_index(Genome& g, const Params& P, const IndexGeom& geo)
+void build_one(const Genome& g, int k, const IndexGeom& geo, IndexView& iv, std::vector<u32>& dirz, std::vector<u32>& ent)
 {
-    g.iv.kb = geo.kb; g.iv.dirbits = geo.dirbits; g.iv.posbits = geo.posbits; g.iv.tagmask = geo.tagmask;
+    iv.kb = geo.kb; iv.dirbits = geo.dirbits; iv.posbits = geo.posbits; iv.tagmask = geo.tagmask;
     size_t nb = (size_t)1 << geo.dirbits;
-    g.dirz.assign(nb + 1, 0);
+    dirz.assign(nb + 1, 0);
     TextView R = g.rview();
     std::vector<std::pair<u32, u32>> items;   // (bucket, entry)
-    for (int p = 0; p + P.mal <= g.T; ++p) {
+    for (int p = 0; p + k <= g.T; ++p) {
         u64 key;
-        if (!kmer_at(R, p, P.mal, key)) continue;
+        if (!kmer_at(R, p, k, key)) continue;
         u32 b, tag;
-        key_slot(g.iv, key, b, tag);
+        key_slot(iv, key, b, tag);
         items.emplace_back(b, (tag << geo.posbits) | (u32)p);
     }
     std::sort(items.begin(), items.end());
-    g.ent.resize(items.size() + 1);
-    for (size_t k = 0; k < items.size(); ++k) { g.ent[k] = items[k].second; g.dirz[items[k].first + 1]++; }
-    for (size_t b = 0; b < nb; ++b) g.dirz[b + 1] += g.dirz[b];
-    g.iv.dirz = g.dirz.data(); g.iv.ent = g.ent.data();
+    ent.resize(items.size() + 1);
+    for (size_t j = 0; j < items.size(); ++j) { ent[j] = items[j].second; dirz[items[j].first + 1]++; }
+    for (size_t b = 0; b < nb; ++b) dirz[b + 1] += dirz[b];
+    iv.dirz = dirz.data(); iv.ent = ent.data();
+}
+void build_index(Genome& g, const Params& P, const IndexGeom& geo)
+{
+    build_one(g, P.mal, geo, g.iv, g.dirz, g.ent);
+}
+// seed (msl) index + per-position k-mer words, for the lane-serial policy
+void build_seed_index(Genome& g, const Params& P, int Tmax)
+{
+    build_one(g, P.msl, index_geometry(Tmax, P.msl), g.sv, g.sdirz, g.sent);
+    TextView R = g.rview();
+    g.kmL.assign((size_t)g.T + 192, 0xFFFFFFFFu);
+    g.kmS.assign((size_t)g.T + 192, 0xFFFFFFFFu);
+    if (P.mal <= 15 && P.msl <= 15)
+        for (int p = 0; p < g.T; ++p) {
+            u64 key;
+            if (kmer_at(R, p, P.mal, key)) g.kmL[p] = (u32)mix_key(key, 2 * P.mal);
+            if (kmer_at(R, p, P.msl, key)) g.kmS[p] = (u32)key;
+        }
 }
 
 struct HostWave {
@@ -139,6 +157,32 @@ int model_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t* len, 
             if (r == q) { o[0] = o[1] = o[2] = 0; continue; }
             HostWave w{P, G[r].rview(), G[q].qview(), G[r].iv};
             PairMachine<HostWave> m(w, P, G[r].T, G[q].D);
+            int res[3];
+            m.run(res);
+            o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+        }
+    return 0;
+}
+
+// The lane-serial policy (thread-per-pair formulation) on the host: out as model_all2all.
+// use_words != 0 feeds it the per-position k-mer words as the device does.
+int model_lane_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t* len, const int32_t* p8, int use_words, int32_t* out)
+{
+    Params P{p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]};
+    if (!params_supported(P)) return -1;
+    uint32_t maxL = 0;
+    for (uint32_t i = 0; i < n; ++i) maxL = std::max(maxL, len[i]);
+    const int Tmax = ref_text_len((int)maxL, P.mrd);
+    IndexGeom geo = index_geometry(Tmax, P.mal);
+    std::vector<Genome> G(n);
+    for (uint32_t i = 0; i < n; ++i) { pack_genome(G[i], codes[i], (int)len[i], P); build_index(G[i], P, geo); build_seed_index(G[i], P, Tmax); }
+    const bool words = use_words && P.mal <= 15 && P.msl <= 15;
+    for (uint32_t r = 0; r < n; ++r)
+        for (uint32_t q = 0; q < n; ++q) {
+            int32_t* o = out + ((size_t)r * n + q) * 3;
+            if (r == q) { o[0] = o[1] = o[2] = 0; continue; }
+            LaneWave w{P, G[r].rview(), G[q].qview(), G[r].iv, G[r].sv, words ? G[q].kmL.data() : nullptr, words ? G[q].kmS.data() : nullptr};
+            PairMachine<LaneWave> m(w, P, G[r].T, G[q].D);
             int res[3];
             m.run(res);
             o[0] = res[0]; o[1] = res[1]; o[2] = res[2];

@@ -270,3 +270,12 @@ def test_mixed_n_content_and_parameter_instantiations():
             want = O.oracle_all2all(data, prm, threads=16)
             bad = np.argwhere((got != want).any(axis=2))
             assert len(bad) == 0, (name, prm, bad[:3].tolist())
+
+
+def test_thread_per_pair_variant(monkeypatch):
+    """The opt-in thread-per-pair kernel (LZANI_KERNEL=tpp; slower, kept for experiments) is bit-exact too."""
+    monkeypatch.setenv("LZANI_KERNEL", "tpp")
+    _, seqs = SG.make_set(40, 5, lmin=4000, lmax=7000, fam=5)
+    seqs[7] = np.concatenate([seqs[7][:1000], np.full(20, 5, np.uint8), seqs[7][1000:]])
+    for prm in (None, dict(mal=13, msl=8, reg=30)):
+        assert np.array_equal(gpu_all2all(seqs, prm), O.oracle_all2all(seqs, prm, threads=16))

@@ -64,3 +64,24 @@ def test_model_regions_stream_equals_calc_regions():
                 res, regs = U.model_pair_regions(E[r], E[q])
                 ores, oregs = O.oracle_pair(E[r], E[q], None, want_regions=True)
                 assert res == ores and np.array_equal(regs, oregs), (r, q)
+
+
+@pytest.mark.parametrize("words", [0, 1])
+def test_lane_serial_policy(words):
+    """LaneWave (lzani_core.h): the same machine driven by one lane per pair with word-parallel bit tricks
+    and a second (msl) index -- the formulation of the thread-per-pair kernel variant."""
+    import ctypes as C
+    lib = U.model_lib()
+
+    def lane(seqs, prm=None):
+        seqs, ptrs, lens = O._seq_table(seqs)
+        n = len(seqs)
+        out = np.zeros((n, n, 3), dtype=np.int32)
+        assert lib.model_lane_all2all(n, ptrs, O._ptr(lens), O.params_array(prm), words, O._ptr(out)) == 0
+        return out
+    _, ex = U.load_example()
+    assert np.array_equal(lane(ex[:8]), O.oracle_all2all(ex[:8], None, threads=8))
+    E = U.edge_set()
+    for prm in (None, dict(mal=15, msl=9, reg=60), dict(mrd=0), dict(ar=1), dict(aw=64, am=20), dict(mqd=64, mrd=64),
+                dict(mqd=0), dict(mal=20, msl=12), dict(ar=0), dict(msl=1, mal=4)):
+        assert np.array_equal(lane(E, prm), O.oracle_all2all(E, prm, threads=8)), prm
