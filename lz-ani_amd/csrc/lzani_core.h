@@ -7,19 +7,20 @@
 //   * texts are 2-bit packed (32 symbols per u64) with a separate N bitmask (64 per u64);
 //     a query is a *prefix view* of its own reference text (R = fwd | N^2mrd | RC | N^mrd,
 //     Q = fwd | N^mrd), so one device copy per genome serves both roles;
-//   * the greedy scan advances in ROUNDS of up to 64 query positions: every lane evaluates
-//     one position speculatively (anchor lookup; for the <= mqd+1 "tracking" steps also the
-//     close-seed search and the probabilistic arbitration) and the first lane that hits
-//     (ballot + ctz) is exactly the step the sequential scan would take, because between
-//     two hits the state evolves affinely (hard part 1);
+//   * the greedy scan advances in ROUNDS of up to 64 query positions: every lane looks at one
+//     position speculatively (anchor candidates; for the <= mqd+1 "tracking" steps also the
+//     close-seed candidates) and the first step that hits (ballot + ctz, verified by the whole
+//     wave) is exactly the step the sequential scan would take, because between two hits the
+//     state evolves affinely (hard part 1);
 //   * no factor list: the calc_stats fold is applied on the fly from mismatch bitmasks
 //     (ballot + popcount + clz), with O(1) state per pair;
 //   * approximate extension consumes 64 symbols per step from a sliding 128-bit mismatch
 //     window instead of a circular flag buffer.
 //
-// The file is shared by the HIP kernels (wave = 64 lanes, lzani_kernels.hip) and by the
-// host-side lane-emulating model used only by the tests (tests/model/): the state machine
-// is templated on a `Wave` policy that supplies the cross-lane primitives.
+// The file is shared by the HIP kernels (wave = 64 lanes, lzani_hip.hip) and by the host-side
+// models used only by the tests (tests/model/): the state machine (PairMachine) is templated on a
+// `Wave` policy that supplies the cross-lane primitives -- DevWave on the device (ballots, LDS),
+// a lane-emulating policy and the lane-serial LaneWave on the host.
 #pragma once
 #include <stdint.h>
 

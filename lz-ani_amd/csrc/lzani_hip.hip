@@ -7,10 +7,13 @@
 //                 per-reference anchor index of all mal-mers (replaces prepare_kmers +
 //                 prepare_ht_long, parser.cpp:53-103, 146-189): bucket directory + (tag|pos)
 //                 entries, ascending inside a bucket
+//   k_kmers       per-genome k-mer words: mixed mal-mer hash and msl-mer of every text position
+//                 (replaces the per-pair prepare_kmers of prepare_data, parser.cpp:46-47)
 //   k_pairs       one wavefront per directed genome pair, persistent waves pulling pairs from
-//                 an atomic cursor in reference-major order (replaces prepare_data + parse +
-//                 calc_stats, parser.cpp:37-50, 482-716, 734-783, and the worker loop of
-//                 do_matching, lz_matcher.cpp:192-269)
+//                 per-XCD work queues (replaces prepare_data + parse + calc_stats,
+//                 parser.cpp:37-50, 482-716, 734-783, and the worker loop of do_matching,
+//                 lz_matcher.cpp:192-269); instantiations FAST/NFREE/DEFP/ALN, see the kernel
+//   k_pairs_tpp   thread-per-pair variant of the same machine (opt-in, LZANI_KERNEL=tpp; slower)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
