@@ -279,3 +279,25 @@ def test_thread_per_pair_variant(monkeypatch):
     seqs[7] = np.concatenate([seqs[7][:1000], np.full(20, 5, np.uint8), seqs[7][1000:]])
     for prm in (None, dict(mal=13, msl=8, reg=30)):
         assert np.array_equal(gpu_all2all(seqs, prm), O.oracle_all2all(seqs, prm, threads=16))
+
+
+def test_degenerate_inputs():
+    """Single genome, empty and sub-k-mer genomes, many tiny genomes: the engine must neither fault nor
+    differ from the oracle (which returns zeros for everything too short to hold a seed)."""
+    eng = L.Engine()
+    one = [SG.make_set(1, 3, lmin=2000, lmax=2100)[1][0]]
+    eng.set_genomes(one)
+    assert eng.all2all().shape == (1, 1, 3)
+    tiny = [np.zeros(0, np.uint8), np.array([0, 1, 2], np.uint8), np.array([3] * 6, np.uint8), one[0][:11].copy(), one[0][:40].copy(), one[0]]
+    eng.set_genomes(tiny)
+    assert np.array_equal(eng.all2all(), O.oracle_all2all(tiny, None, threads=4))
+    st = SG.Stream(8)
+    many = [(st.u64(st.randint(60, 140)) % np.uint64(4)).astype(np.uint8) for _ in range(600)]
+    many[5] = many[4].copy()
+    many[9] = (3 - many[4][::-1]).astype(np.uint8)
+    eng.set_genomes(many)
+    got = eng.all2all()
+    eng.close()
+    want = O.oracle_all2all(many, None, threads=16)
+    assert np.array_equal(got, want)
+    assert got[4, 5, 0] == len(many[4]) and got[4, 9, 0] == len(many[4])
