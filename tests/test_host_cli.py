@@ -133,6 +133,24 @@ def test_ingest_quirks(tmp_path):
     assert (tmp_path / "o.ids.tsv").read_text() == "id\tseq_len\tno_parts\nq.fna\t66\t1\n"       # 16 + 40 + 10
 
 
+def test_gz_and_in_txt_inputs(tmp_path):
+    """gzip-compressed FASTA (file_wrapper.h:472-606 in the reference) and --in-txt give the same files."""
+    import gzip
+    names, seqs, res = _oracle_reordered(U.load_example)
+    raw = str(tmp_path / "raw.txt")
+    _raw_file(raw, res)
+    fa = os.path.join(U.GOLD, "example", "multifasta.fna")
+    gz = str(tmp_path / "multi.fna.gz")
+    with open(fa, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    lst = tmp_path / "list.txt"
+    lst.write_text(gz + "\n")
+    for args in (["--in-fasta", gz], ["--in-txt", str(lst)]):
+        out = str(tmp_path / "o.tsv")
+        assert run(["all2all"] + args + ["-o", out, "--results-in", raw]).returncode == 0
+        assert open(out).read() == open(os.path.join(U.GOLD, "example", "ani.tsv")).read()
+
+
 @pytest.mark.gpu
 def test_end_to_end_on_gpu(tmp_path):
     """The whole binary on the GPU: vir61 (config 1) and the example set with and without the filter."""
