@@ -115,7 +115,8 @@ LZ_HD int iabs(int a) { return a < 0 ? -a : a; }
 // 32 symbols (64 bits) starting at symbol p >= 0
 LZ_HD u64 win2(const u64* t2, int p)
 {
-    int w = p >> 5, s = (p & 31) * 2;
+    const u32 w = (u32)p >> 5;               // unsigned index: 32-bit offset addressing on the device
+    const int s = (p & 31) * 2;
     u64 lo = t2[w];
     if (s == 0) return lo;
     return (lo >> s) | (t2[w + 1] << (64 - s));
@@ -123,13 +124,14 @@ LZ_HD u64 win2(const u64* t2, int p)
 // 64 N flags starting at symbol p >= 0
 LZ_HD u64 winN(const u64* nm, int p)
 {
-    int w = p >> 6, s = p & 63;
+    const u32 w = (u32)p >> 6;
+    const int s = p & 63;
     u64 lo = nm[w];
     if (s == 0) return lo;
     return (lo >> s) | (nm[w + 1] << (64 - s));
 }
-LZ_HD int sym_at(const TextView& t, int p) { return (int)((t.t2[p >> 5] >> ((p & 31) * 2)) & 3ULL); }
-LZ_HD int isN_at(const TextView& t, int p) { return (int)((t.nm[p >> 6] >> (p & 63)) & 1ULL); }
+LZ_HD int sym_at(const TextView& t, int p) { return (int)((t.t2[(u32)p >> 5] >> ((p & 31) * 2)) & 3ULL); }
+LZ_HD int isN_at(const TextView& t, int p) { return (int)((t.nm[(u32)p >> 6] >> (p & 63)) & 1ULL); }
 
 // 1 iff both positions exist, neither is N, and the symbols are equal.  N never matches
 // anything (reference: code_N_ref = 4 vs code_N_seq = 5, defs.h:28-30).

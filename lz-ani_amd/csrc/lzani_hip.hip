@@ -376,13 +376,13 @@ struct DevWave {
 
         // every independent load of the round first, unconditionally (the k-mer arrays are padded by two
         // 64-entry blocks, so the addresses are always in bounds) and masked afterwards: no branches
-        u32 hq = qkL[i + lane], rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
+        u32 hq = qkL[(u32)(i + lane)], rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
         hq = lane < n ? hq : KM_INVALID;
         if (W > 0) {                                                 // wave-uniform
             const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
-            qk = qkS[i + lane];
-            rk0 = rkS[r_end + w0];
-            rk1 = rkS[r_end + w1];
+            qk = qkS[(u32)(i + lane)];
+            rk0 = rkS[(u32)(r_end + w0)];
+            rk1 = rkS[(u32)(r_end + w1)];
             qk = lane < nt ? qk : KM_INVALID;
             rk0 = lane < W ? rk0 : KM_INVALID;
             rk1 = lane + 64 < W ? rk1 : KM_INVALID;
