@@ -13,6 +13,11 @@
  * exit(); lzani_last_error() gives the message.  A context is bound to one GPU, is blocking
  * and not re-entrant (the reference's per-thread CParser has the same property, parser.h:25-56).
  * Outputs are written only on success.
+ *
+ * Results are bit-identical to the reference's for every parameter set with max_dist_in_query <=
+ * max_dist_in_ref (all defaults and published settings).  Above that the reference reads beyond the end
+ * of its reference text (undefined behaviour); this engine treats positions outside a text as never
+ * matching, deterministically.
  */
 #ifndef LZANI_H
 #define LZANI_H

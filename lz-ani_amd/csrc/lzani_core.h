@@ -70,7 +70,11 @@ LZ_HD TextView qry_view(const u64* t2, const u64* nm, int L, int mrd, bool nfree
 LZ_HD bool pos_valid(const TextView& t, int p)      // branch-free: unsigned range tests, bitwise combination
 { return ((u32)p < (u32)t.L) | ((t.rc0 >= 0) & ((u32)(p - t.rc0) < (u32)t.L)); }
 LZ_HD int run_end(const TextView& t, int p)
-{ return p < t.L ? t.L : ((t.rc0 >= 0 && p >= t.rc0 && p < t.rc0 + t.L) ? t.rc0 + t.L : p); }
+{
+    // with mrd = 0 no pad separates the forward part from the reverse complement: one run [0, 2L)
+    if (p < t.L) return (t.rc0 == t.L) ? t.rc0 + t.L : t.L;
+    return (t.rc0 >= 0 && p >= t.rc0 && p < t.rc0 + t.L) ? t.rc0 + t.L : p;
+}
 
 struct IndexView {        // anchor index of one reference (all mal-mers of R)
     const u32* dirz;      // dirz[b] .. dirz[b+1] = entry range of bucket b

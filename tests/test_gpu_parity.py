@@ -301,3 +301,14 @@ def test_degenerate_inputs():
     want = O.oracle_all2all(many, None, threads=16)
     assert np.array_equal(got, want)
     assert got[4, 5, 0] == len(many[4]) and got[4, 9, 0] == len(many[4])
+
+
+def test_differential_fuzz_gpu_vs_oracle():
+    """Seeded random parameters (every instantiation and fallback path gets hit) and sequences through
+    the C-ABI against the oracle."""
+    st = SG.Stream(4242)
+    for it in range(120):
+        prm, seqs = U.fuzz_case(st)
+        got = gpu_all2all(seqs, prm)
+        want = O.oracle_all2all(seqs, prm, threads=4)
+        assert np.array_equal(got, want), (it, prm, np.argwhere((got != want).any(axis=2))[:3].tolist())

@@ -85,3 +85,22 @@ def test_lane_serial_policy(words):
     for prm in (None, dict(mal=15, msl=9, reg=60), dict(mrd=0), dict(ar=1), dict(aw=64, am=20), dict(mqd=64, mrd=64),
                 dict(mqd=0), dict(mal=20, msl=12), dict(ar=0), dict(msl=1, mal=4)):
         assert np.array_equal(lane(E, prm), O.oracle_all2all(E, prm, threads=8)), prm
+
+
+def test_differential_fuzz_models_vs_oracle():
+    """Seeded random parameters and sequences: both host models of the kernel formulation against the
+    oracle (and the oracle against the reference build where present).  This is the test that found the
+    mrd = 0 case (no pad between the forward text and its reverse complement)."""
+    import ctypes as C
+    lib = U.model_lib()
+    st = SG.Stream(2024)
+    for it in range(250):
+        prm, seqs = U.fuzz_case(st)
+        want = O.oracle_all2all(seqs, prm, threads=4)
+        assert np.array_equal(U.model_all2all(seqs, prm), want), (it, prm)
+        s, ptrs, lens = O._seq_table(seqs)
+        out = np.zeros((len(s), len(s), 3), dtype=np.int32)
+        assert lib.model_lane_all2all(len(s), ptrs, O._ptr(lens), O.params_array(prm), it & 1, O._ptr(out)) == 0
+        assert np.array_equal(out, want), (it, prm)
+        if O.lib_ref() is not None and it % 4 == 0:
+            assert np.array_equal(O.ref_all2all(seqs, prm, threads=4), want), (it, prm)

@@ -183,3 +183,33 @@ def model_pair_regions(ref, qry, params=None):
     g = regs[:n.value]
     order = sorted(range(len(g)), key=lambda k: (-(int(g[k][3]) - int(g[k][2])), int(g[k][2])))
     return tuple(int(x) for x in res), g[order]
+
+
+def fuzz_case(st):
+    """One random differential case: LZ parameters inside the engine's envelope with mqd <= mrd (beyond
+    that the reference reads past the end of its reference text, parser.cpp:288/713, and its answer
+    depends on stale heap bytes), and five short genomes: an ancestor, mutated copies, unrelated
+    sequences, N runs, reverse complements, low-complexity repeats."""
+    msl = st.randint(1, 12)
+    mal = st.randint(msl, min(16, msl + 8))
+    mrd = st.randint(0, 64)
+    prm = dict(mal=mal, msl=msl, mrd=mrd, mqd=st.randint(0, mrd), reg=st.randint(1, 80), aw=st.randint(1, 64),
+               am=st.randint(0, 20), ar=st.randint(0, 12))
+    base = (st.u64(st.randint(50, 1500)) % np.uint64(4)).astype(np.uint8)
+    seqs = [base]
+    for _ in range(4):
+        if st.one() < 0.8:
+            g = SG.mutate(base, 0.01 + 0.25 * st.one(), st)
+        else:
+            g = (st.u64(st.randint(20, 1500)) % np.uint64(4)).astype(np.uint8)
+        if st.one() < 0.3:
+            g = g.copy()
+            a = st.randint(0, max(0, len(g) - 10))
+            g[a:a + st.randint(1, 30)] = 5
+        if st.one() < 0.2:
+            g = (3 - g[::-1]).astype(np.uint8)
+            g[g > 3] = 5
+        if st.one() < 0.15:
+            g = np.tile(g[:st.randint(1, 6)], 60)[:400]
+        seqs.append(np.ascontiguousarray(g))
+    return prm, seqs

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Long differential fuzz of the HIP path against the oracle.  Usage: tools/fuzz_gpu.py [seed] [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("lz-ani_amd", "oracle", "tools", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np
+import lzani_ctypes as L
+import oracle as O
+import synth_genomes as SG
+import util as U
+
+st = SG.Stream(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
+t0, it, bad = time.time(), 0, 0
+while time.time() - t0 < budget:
+    it += 1
+    prm, seqs = U.fuzz_case(st)
+    eng = L.Engine(prm)
+    eng.set_genomes(seqs)
+    got = eng.all2all()
+    eng.close()
+    want = O.oracle_all2all(seqs, prm, threads=4)
+    if not np.array_equal(got, want):
+        bad += 1
+        print("MISMATCH", prm, [len(s) for s in seqs], np.argwhere((got != want).any(axis=2))[:3].tolist(), flush=True)
+    if it % 500 == 0:
+        print("...", it, "cases", flush=True)
+print("cases", it, "mismatches", bad)
+sys.exit(1 if bad else 0)
