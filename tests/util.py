@@ -190,10 +190,11 @@ def fuzz_case(st):
     that the reference reads past the end of its reference text, parser.cpp:288/713, and its answer
     depends on stale heap bytes), and five short genomes: an ancestor, mutated copies, unrelated
     sequences, N runs, reverse complements, low-complexity repeats."""
-    msl = st.randint(1, 12)
-    mal = st.randint(msl, min(16, msl + 8))
-    mrd = st.randint(0, 64)
-    prm = dict(mal=mal, msl=msl, mrd=mrd, mqd=st.randint(0, mrd), reg=st.randint(1, 80), aw=st.randint(1, 64),
+    wide = st.one() < 0.2                      # long k-mers / wide seed windows: the engine's generic paths
+    msl = st.randint(1, 20 if wide else 12)
+    mal = st.randint(msl, min(28 if wide else 16, msl + 8))
+    mrd = st.randint(0, 300 if wide else 64)
+    prm = dict(mal=mal, msl=msl, mrd=mrd, mqd=st.randint(0, min(mrd, 64)), reg=st.randint(1, 80), aw=st.randint(1, 64),
                am=st.randint(0, 20), ar=st.randint(0, 12))
     base = (st.u64(st.randint(50, 1500)) % np.uint64(4)).astype(np.uint8)
     seqs = [base]

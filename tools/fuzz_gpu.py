@@ -19,11 +19,28 @@ while time.time() - t0 < budget:
     eng = L.Engine(prm)
     eng.set_genomes(seqs)
     got = eng.all2all()
-    eng.close()
     want = O.oracle_all2all(seqs, prm, threads=4)
     if not np.array_equal(got, want):
         bad += 1
         print("MISMATCH", prm, [len(s) for s in seqs], np.argwhere((got != want).any(axis=2))[:3].tolist(), flush=True)
+    if it % 4 == 0:                                   # the alignment instantiation: regions of one row
+        n = len(seqs)
+        r = it % n
+        ref_ids, row_off = L.dense_rows(n, [r])
+        out, regs = eng.run_rows_regions(ref_ids, row_off, None, capacity=256)
+        e = 0
+        for q in range(n):
+            if q == r:
+                continue
+            mine = regs[regs["pair"] == e]
+            cols = ("ref_start", "ref_end", "seq_start", "seq_end", "num_matches", "num_mismatches")
+            g = np.stack([mine[k] for k in cols], axis=1) if len(mine) else np.zeros((0, 6), np.int32)
+            ores, oregs = O.oracle_pair(seqs[r], seqs[q], prm, want_regions=True)
+            if tuple(out[e]) != ores or not np.array_equal(g, oregs):
+                bad += 1
+                print("REGIONS MISMATCH", prm, [len(s) for s in seqs], r, q, flush=True)
+            e += 1
+    eng.close()
     if it % 500 == 0:
         print("...", it, "cases", flush=True)
 print("cases", it, "mismatches", bad)
