@@ -104,8 +104,19 @@ def lib_ref():
                                  C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.ref_rows.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        if hasattr(lib, "ref_format_real"):
+            lib.ref_format_real.argtypes = [C.c_double, C.c_int, C.c_char_p]
         _ref = lib
     return _ref
+
+
+def ref_format_real(v, prec):
+    """refresh::real_to_pchar of the reference build (the TSV number formatting)."""
+    lib = lib_ref()
+    assert lib is not None, "oracle/_ref not built"
+    buf = C.create_string_buffer(64)
+    n = lib.ref_format_real(float(v), int(prec), buf)
+    return buf.raw[:n].decode()
 
 
 def _ptr(a):

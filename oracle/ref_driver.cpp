@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "parser.h"   // the reference's header, found through -I/root/reference/src
+#include "../libs/refresh/conversions/lib/numeric_conversions.h"   // the reference's number formatting (header only)
 
 namespace {
 
@@ -109,6 +110,14 @@ int ref_rows(uint32_t n, const uint8_t* const* codes, const uint32_t* len, const
         for (auto& t : th) t.join();
     }
     return 0;
+}
+
+// refresh::real_to_pchar (numeric_conversions.h:341-390): the TSV number formatting, for pinning the
+// host emitter.  Returns the length written (no terminator counted).
+int ref_format_real(double v, int prec, char* out)
+{
+    size_t n = refresh::real_to_pchar(v, out, (size_t)prec, (char)0);
+    return (int)n - 1;
 }
 
 }  // extern "C"

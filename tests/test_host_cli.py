@@ -133,6 +133,42 @@ def test_ingest_quirks(tmp_path):
     assert (tmp_path / "o.ids.tsv").read_text() == "id\tseq_len\tno_parts\nq.fna\t66\t1\n"       # 16 + 40 + 10
 
 
+def test_number_formatting_against_reference_and_restatement():
+    """The emitter's real_to_chars (lz-ani_amd/host/emit.h) against the Python restatement used by the golden
+    rebuilds and, where oracle/_ref exists, against the reference's own refresh::real_to_pchar."""
+    import ctypes as C
+    import random
+    import struct
+    d = os.path.join(U.ROOT, "tests", "model")
+    so = os.path.join(d, "libemit_shim.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", os.path.join(d, "emit_shim.cpp"), "-o", so, "-lz"])
+    lib = C.CDLL(so)
+    lib.host_format_real.argtypes = [C.c_double, C.c_int, C.c_char_p]
+    buf = C.create_string_buffer(64)
+    have_ref = O.lib_ref() is not None and hasattr(O.lib_ref(), "ref_format_real")
+    rnd = random.Random(3)
+    vals = [0.0, 1.0, 0.5, 1e-7, 4e-7, 0.000364, 0.98725, 0.999999, 0.9999995, 0.99999949, 9.9999995, 123456.5,
+            1234567.0, 1e21, 1e22, 5e-324, 1.7976931348623157e308]
+    for _ in range(20000):
+        k = rnd.random()
+        if k < 0.5:
+            v = rnd.randint(0, 10 ** rnd.randint(1, 7)) / rnd.randint(1, 10 ** rnd.randint(1, 7))
+        elif k < 0.7:
+            v = 100.0 * rnd.randint(0, 50000) / rnd.randint(1, 50000)
+        elif k < 0.9:
+            v = rnd.random() * 10 ** rnd.randint(-12, 12)
+        else:
+            v = struct.unpack("d", struct.pack("Q", rnd.getrandbits(62)))[0]
+        if v == v and v != float("inf"):
+            vals.append(v)
+    for i, v in enumerate(vals):
+        prec = (4, 6, 6, 6, 1, 2, 9, 15)[i % 8]
+        mine = buf.raw[:lib.host_format_real(v, prec, buf)].decode()
+        assert mine == U.real_to_str(v, prec), (v, prec)
+        if have_ref:
+            assert mine == O.ref_format_real(v, prec), (v, prec)
+
+
 def test_gz_and_in_txt_inputs(tmp_path):
     """gzip-compressed FASTA (file_wrapper.h:472-606 in the reference) and --in-txt give the same files."""
     import gzip
