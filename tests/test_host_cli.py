@@ -163,7 +163,8 @@ def test_number_formatting_against_reference_and_restatement():
             vals.append(v)
     for i, v in enumerate(vals):
         prec = (4, 6, 6, 6, 1, 2, 9, 15)[i % 8]
-        mine = buf.raw[:lib.host_format_real(v, prec, buf)].decode()
+        n = lib.host_format_real(v, prec, buf)
+        mine = buf.raw[:n].decode()
         assert mine == U.real_to_str(v, prec), (v, prec)
         if have_ref:
             assert mine == O.ref_format_real(v, prec), (v, prec)
