@@ -110,6 +110,16 @@ def lib_ref():
     return _ref
 
 
+def ref_expand_output_format(fmt):
+    """Column names the reference derives from an --out-format string ("!token" if it rejects one)."""
+    lib = lib_ref()
+    assert lib is not None, "oracle/_ref not built"
+    buf = C.create_string_buffer(4096)
+    lib.ref_expand_output_format.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    n = lib.ref_expand_output_format(fmt.encode(), buf, 4096)
+    return buf.raw[:n].decode()
+
+
 def ref_format_real(v, prec):
     """refresh::real_to_pchar of the reference build (the TSV number formatting)."""
     lib = lib_ref()

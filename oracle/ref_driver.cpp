@@ -120,4 +120,19 @@ int ref_format_real(double v, int prec, char* out)
     return (int)n - 1;
 }
 
+// CParams::std_comp / parse_output_format (params.h:65-69, 169-198): the expansion of an --out-format
+// string into column names, comma separated; "!<token>" if the reference rejects a component.
+int ref_expand_output_format(const char* fmt, char* out, int cap)
+{
+    CParams p;
+    std::string bad = p.parse_output_format(fmt);
+    std::string s;
+    if (!bad.empty()) s = "!" + bad;
+    else
+        for (auto c : p.output_components) { if (!s.empty()) s += ","; s += p.comp_id_name[c]; }
+    if ((int)s.size() + 1 > cap) return -1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
 }  // extern "C"

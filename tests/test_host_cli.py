@@ -170,6 +170,22 @@ def test_number_formatting_against_reference_and_restatement():
             assert mine == O.ref_format_real(v, prec), (v, prec)
 
 
+@pytest.mark.skipif(O.lib_ref() is None or not hasattr(O.lib_ref(), "ref_expand_output_format"), reason="oracle/_ref not built")
+def test_out_format_expansion_matches_reference(tmp_path):
+    """--out-format meta names and column lists: the header the binary writes is what CParams derives."""
+    names, seqs, res = _oracle_reordered(U.load_example)
+    raw = str(tmp_path / "raw.txt")
+    _raw_file(raw, res)
+    fa = os.path.join(U.GOLD, "example", "multifasta.fna")
+    for fmt in ("standard", "lite", "complete", "lite,rlen,qlen", "nt_match,standard", "query,reference,tani", "rcov"):
+        out = str(tmp_path / "f.tsv")
+        assert run(["all2all", "--in-fasta", fa, "-o", out, "--results-in", raw, "--out-format", fmt]).returncode == 0
+        assert open(out).readline().rstrip("\n").split("\t") == O.ref_expand_output_format(fmt).split(",")
+    assert O.ref_expand_output_format("tani,bogus") == "!bogus"
+    p = run(["all2all", "--in-fasta", fa, "-o", str(tmp_path / "g.tsv"), "--results-in", raw, "--out-format", "tani,bogus"])
+    assert p.returncode == 0 and "Unknown output-format component: bogus" in p.stderr      # parse failure: return 0, as the reference
+
+
 def test_gz_and_in_txt_inputs(tmp_path):
     """gzip-compressed FASTA (file_wrapper.h:472-606 in the reference) and --in-txt give the same files."""
     import gzip
