@@ -83,7 +83,10 @@ struct IndexView {        // anchor index of one reference (all mal-mers of R)
     int dirbits;          // bucket = top dirbits of mix(key)
     int posbits;          // low bits of an entry hold the position
     u32 tagmask;          // stored tag bits
+    const u32* bk;        // optional bucket table: 4 entries per bucket (BK_EMPTY padded; entry 3 = BK_OVERFLOW
+                          // when the bucket holds more than four), or nullptr
 };
+enum : u32 { BK_EMPTY = 0xFFFFFFFFu, BK_OVERFLOW = 0xFFFFFFFEu };
 
 // ---- bit helpers --------------------------------------------------------------------
 LZ_HD u64 lowmask(int n) { return n >= 64 ? ~0ULL : (n <= 0 ? 0ULL : ((1ULL << n) - 1ULL)); }

@@ -206,6 +206,26 @@ __global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, 
     }
 }
 
+// Bucket table: the first four entries of every bucket side by side (16 B), so that a round reaches its
+// anchor candidates with one load after the k-mer word instead of directory + entries.
+__global__ void k_idx_buckets(const u32* __restrict__ dirz, const u32* __restrict__ ent, u32* __restrict__ bk,
+                              u64 dir_stride, u64 ent_stride, u64 bk_stride, u32 nb)
+{
+    u32 slot = blockIdx.y;
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const u32* d = dirz + slot * dir_stride;
+    const u32* v = ent + slot * ent_stride;
+    const u32 s = d[b], e = d[b + 1];
+    uint4 o;
+    o.x = s < e ? v[s] : BK_EMPTY;
+    o.y = s + 1 < e ? v[s + 1] : BK_EMPTY;
+    o.z = s + 2 < e ? v[s + 2] : BK_EMPTY;
+    o.w = s + 3 < e ? v[s + 3] : BK_EMPTY;
+    if (e - s > 4) o.w = BK_OVERFLOW;
+    reinterpret_cast<uint4*>(bk + slot * bk_stride)[b] = o;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_pairs: the pair kernel.
 // ------------------------------------------------------------------------------------------
@@ -387,23 +407,26 @@ struct DevWave {
             rk0 = lane < W ? rk0 : KM_INVALID;
             rk1 = lane + 64 < W ? rk1 : KM_INVALID;
         }
-        // anchor candidates: first bucket entry with this step's tag, and how many follow.  Buckets
-        // hold ~0.6 entries: the first four are fetched at once (clamped indices, one wait), a loop
-        // only serves the rare longer bucket.
+        // anchor candidates of this lane's step: bucket entries carrying the step's (exact) tag.
+        //   bucket table present: one 16-byte load brings the bucket's first four entries, which stay in
+        //   registers for the verify step; a fifth+ entry (BK_OVERFLOW, ~0.03 % of buckets) sends the lane
+        //   through the directory;  no bucket table (large genomes): directory + entries.
         u32 aj = 0, ac = 0;
+        uint4 bkv = {BK_EMPTY, BK_EMPTY, BK_EMPTY, BK_EMPTY};
+        bool viadir = I.bk == nullptr;
         if (hq != KM_INVALID) {
             const u32 b = hq >> tb, tag = hq & I.tagmask;
-            u32 s = I.dirz[b], e = I.dirz[b + 1];
-            if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
-            const u32 cnt = e - s;
-            if (cnt) {
-                const u32 last = e - 1;
-                const u32 e0 = I.ent[s], e1 = I.ent[min(s + 1, last)], e2 = I.ent[min(s + 2, last)], e3 = I.ent[min(s + 3, last)];
-                const bool m0 = (e0 >> I.posbits) == tag, m1 = cnt > 1 && (e1 >> I.posbits) == tag,
-                           m2 = cnt > 2 && (e2 >> I.posbits) == tag, m3 = cnt > 3 && (e3 >> I.posbits) == tag;
-                ac = (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
-                aj = s + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
-                for (u32 j = s + 4; j < e; ++j) {
+            if (I.bk) {
+                bkv = reinterpret_cast<const uint4*>(I.bk)[b];
+                viadir = bkv.w == BK_OVERFLOW;
+                if (!viadir)                              // BK_EMPTY never carries a real tag (tag + position bits <= 30)
+                    ac = (u32)((bkv.x >> I.posbits) == tag) + (u32)((bkv.y >> I.posbits) == tag) +
+                         (u32)((bkv.z >> I.posbits) == tag) + (u32)((bkv.w >> I.posbits) == tag);
+            }
+            if (viadir) {
+                u32 s = I.dirz[b], e = I.dirz[b + 1];
+                if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
+                for (u32 j = s; j < e; ++j) {
                     const bool m = (I.ent[j] >> I.posbits) == tag;
                     aj = (m && ac == 0) ? j : aj;
                     ac += m;
@@ -421,11 +444,27 @@ struct DevWave {
             todo &= todo - 1;
             const int qp = i + l;
             int ap = 0, al = 0;
-            const u32 j0 = __builtin_amdgcn_readlane(aj, l), cnt = __builtin_amdgcn_readlane(ac, l);
-            for (u32 k = 0; k < cnt; ++k) {                          // same k-mer, ascending position
-                const int p = (int)(I.ent[j0 + k] & pm);
-                const int m = wave_equal_len(p, qp, 0);
-                if (m >= P.mal && m > al) { al = m; ap = p; }
+            const u32 cnt = __builtin_amdgcn_readlane(ac, l);
+            if (cnt) {
+                if (__builtin_amdgcn_readlane((int)viadir, l)) {
+                    const u32 j0 = __builtin_amdgcn_readlane(aj, l);
+                    for (u32 k = 0; k < cnt; ++k) {                  // same k-mer, ascending position
+                        const int p = (int)(I.ent[j0 + k] & pm);
+                        const int m = wave_equal_len(p, qp, 0);
+                        if (m >= P.mal && m > al) { al = m; ap = p; }
+                    }
+                } else {                                             // the step's bucket is still in registers
+                    const u32 tag = (u32)__builtin_amdgcn_readlane((int)hq, l) & I.tagmask;
+                    const u32 en[4] = {(u32)__builtin_amdgcn_readlane((int)bkv.x, l), (u32)__builtin_amdgcn_readlane((int)bkv.y, l),
+                                       (u32)__builtin_amdgcn_readlane((int)bkv.z, l), (u32)__builtin_amdgcn_readlane((int)bkv.w, l)};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if ((en[k] >> I.posbits) != tag) continue;
+                        const int p = (int)(en[k] & pm);
+                        const int m = wave_equal_len(p, qp, 0);
+                        if (m >= P.mal && m > al) { al = m; ap = p; }
+                    }
+                }
             }
             int bp = ap, bl = al;
             if (l < nt) {
@@ -472,6 +511,8 @@ struct PairArgs {
     const u32* dirz;
     const u32* ent;
     u64 dir_stride, ent_stride;
+    const u32* bk;           // bucket tables (4 entries per bucket) or nullptr
+    u64 bk_stride;
     const u32* ref_ids;      // device, batch-relative rows
     const u64* row_off;      // device, batch-relative rows (+1), absolute pair offsets
     const u32* query_ids;    // device, absolute pair offsets, or nullptr for dense rows
@@ -543,6 +584,7 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         iv.dirz = a.dirz + slot * a.dir_stride;
         iv.ent = a.ent + slot * a.ent_stride;
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
+        iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
         const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
         DevWave<FAST> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                         qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
@@ -612,6 +654,7 @@ __global__ void __launch_bounds__(256) k_pairs_tpp(TppArgs ta)
         iv.dirz = a.dirz + slot * a.dir_stride;
         iv.ent = a.ent + slot * a.ent_stride;
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
+        iv.bk = nullptr; sv.bk = nullptr;
         sv.dirz = ta.sdirz + slot * ta.sdir_stride;
         sv.ent = ta.sent + slot * ta.sent_stride;
         sv.kb = ta.sgeo.kb; sv.dirbits = ta.sgeo.dirbits; sv.posbits = ta.sgeo.posbits; sv.tagmask = ta.sgeo.tagmask;
@@ -659,6 +702,8 @@ struct lzani_ctx {
 
     u32* d_dirz = nullptr;
     u32* d_ent = nullptr;
+    u32* d_bk = nullptr;          // bucket tables (viral-size directories only)
+    u64 bk_stride = 0;
     u32* d_sdirz = nullptr;       // seed (msl) index slabs, thread-per-pair kernel only
     u32* d_sent = nullptr;
     u64 sdir_stride = 0;
@@ -716,8 +761,8 @@ void free_genomes(lzani_ctx* c)
 }
 void free_slabs(lzani_ctx* c)
 {
-    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_sdirz); hipFree(c->d_sent);
-    c->d_dirz = c->d_ent = c->d_sdirz = c->d_sent = nullptr; c->slots = 0;
+    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_sdirz); hipFree(c->d_sent); hipFree(c->d_bk);
+    c->d_dirz = c->d_ent = c->d_sdirz = c->d_sent = c->d_bk = nullptr; c->slots = 0;
 }
 
 int ensure_slabs(lzani_ctx* c, u32 want_rows)
@@ -729,7 +774,15 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
         c->use_tpp = e && !strcmp(e, "tpp") && c->d_kmL &&
                      c->sgeo.tagmask == (u32)lowmask(c->sgeo.kb - c->sgeo.dirbits);
     }
-    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + (c->use_tpp ? c->sdir_stride + c->ent_stride : 0));
+    {   // bucket table: only where it stays L2-sized (<= 2^18 buckets) and the sentinels cannot be real entries
+        int tagbits = 0;
+        while (tagbits < 32 && ((c->geo.tagmask >> tagbits) & 1u)) ++tagbits;
+        const bool exact = c->geo.tagmask == (u32)lowmask(c->geo.kb - c->geo.dirbits);
+        const char* e = getenv("LZANI_NO_BUCKETS");
+        c->bk_stride = (c->d_kmL && exact && c->geo.dirbits <= 18 && tagbits + c->geo.posbits <= 30 && !(e && *e == '1'))
+                           ? ((u64)4 << c->geo.dirbits) : 0;
+    }
+    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + (c->use_tpp ? c->sdir_stride + c->ent_stride : 0));
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     size_t have = c->slots * per_slot;
@@ -739,6 +792,7 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     free_slabs(c);
     HIPCHK(c, hipMalloc(&c->d_dirz, (size_t)slots * c->dir_stride * 4));
     HIPCHK(c, hipMalloc(&c->d_ent, (size_t)slots * c->ent_stride * 4));
+    if (c->bk_stride) HIPCHK(c, hipMalloc(&c->d_bk, (size_t)slots * c->bk_stride * 4));
     if (c->use_tpp) {
         HIPCHK(c, hipMalloc(&c->d_sdirz, (size_t)slots * c->sdir_stride * 4));
         HIPCHK(c, hipMalloc(&c->d_sent, (size_t)slots * c->ent_stride * 4));
@@ -777,6 +831,9 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
     hipLaunchKernelGGL(k_idx_fill, gp, dim3(256), 0, c->stream, ia, c->Tmax);
     hipLaunchKernelGGL(k_idx_sort, dim3((nb + 255) / 256, rows), dim3(256), 0, c->stream,
                        c->d_dirz, c->d_ent, c->dir_stride, c->ent_stride, nb);
+    if (c->d_bk)
+        hipLaunchKernelGGL(k_idx_buckets, dim3((nb + 255) / 256, rows), dim3(256), 0, c->stream,
+                           c->d_dirz, c->d_ent, c->d_bk, c->dir_stride, c->ent_stride, c->bk_stride, nb);
     if (c->use_tpp) {                             // second index over the msl-mers
         IdxArgs sa = ia;
         sa.dirz = c->d_sdirz; sa.ent = c->d_sent; sa.dir_stride = c->sdir_stride;
@@ -854,6 +911,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.P = c->P; pa.geo = c->geo;
             pa.dirz = c->d_dirz; pa.ent = c->d_ent;
             pa.dir_stride = c->dir_stride; pa.ent_stride = c->ent_stride;
+            pa.bk = c->d_bk; pa.bk_stride = c->bk_stride;
             pa.ref_ids = d_ref + k0; pa.row_off = d_off + k0; pa.query_ids = d_q;
             pa.out = d_out; pa.cursor = c->d_cursor;
             // rows -> queues: longest row first onto the least loaded queue (equal rows: round robin)

@@ -49,7 +49,7 @@ void pack_genome(Genome& g, const uint8_t* codes, int L, const Params& P)
 
 void build_one(const Genome& g, int k, const IndexGeom& geo, IndexView& iv, std::vector<u32>& dirz, std::vector<u32>& ent)
 {
-    iv.kb = geo.kb; iv.dirbits = geo.dirbits; iv.posbits = geo.posbits; iv.tagmask = geo.tagmask;
+    iv.kb = geo.kb; iv.dirbits = geo.dirbits; iv.posbits = geo.posbits; iv.tagmask = geo.tagmask; iv.bk = nullptr;
     size_t nb = (size_t)1 << geo.dirbits;
     dirz.assign(nb + 1, 0);
     TextView R = g.rview();
