@@ -115,6 +115,16 @@ LZ_HD int clz64(u64 x)      // x != 0
     return __builtin_clzll(x);
 #endif
 }
+LZ_HD u64 brev64(u64 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    u64 r = 0;
+    for (int k = 0; k < 64; ++k) r |= ((x >> k) & 1ULL) << (63 - k);
+    return r;
+#endif
+}
 LZ_HD int imin(int a, int b) { return a < b ? a : b; }
 LZ_HD int imax(int a, int b) { return a > b ? a : b; }
 LZ_HD int iabs(int a) { return a < 0 ? -a : a; }
@@ -418,6 +428,7 @@ LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool
 //                                   first step l in [0,n) whose evaluation gives len >= msl
 //   ExtMasks ext_scan(prevB, B, n)
 //   int  best_split(Lm, Rm, to_scan) argmax_s popc(Lm & low(s)) + popc(Rm >> s), last max wins
+//   void mism_fb(fq, fr, nf, bq, br, nb, Bf, Bb)   Bf = mism_fwd(fq, fr, nf), Bb = mism_bwd(bq, br, nb), one fetch
 //   void stamp(section)             profiling hook (no-op outside the LZANI_STAMPS diagnostic build)
 //   void emit_region(RegionCoords)  ALN only: one region of calc_regions (length >= reg)
 template <class W, bool ALN = false>
@@ -466,14 +477,15 @@ struct PairMachine {
     }
 
     // try_extend_forward (parser.cpp:377-409) fused with the fold of compare_ranges(i, ref_pred, e)
-    LZ_HD int extend_forward(int q0, int r0)
+    // have0/B0: the mismatch mask of the first chunk, if the caller fetched it already (mism_fb)
+    LZ_HD int extend_forward(int q0, int r0, bool have0 = false, u64 B0 = 0)
     {
         int maxlen = imin(D - q0, T - r0);
         int last = 0, last_mm = 0, mm_cum = 0;
         u64 prevB = 0;
         for (int base = 0; base < maxlen; base += 64) {
             int n = imin(64, maxlen - base);
-            u64 B = w.mism_fwd(q0 + base, r0 + base, n);
+            u64 B = (have0 && base == 0) ? B0 : w.mism_fwd(q0 + base, r0 + base, n);
             ExtMasks m = w.ext_scan(prevB, B, n);
             u64 qm = m.qual;
             if (m.brk) qm &= lowmask(ctz64(m.brk) + 1);
@@ -501,14 +513,14 @@ struct PairMachine {
     }
 
     // try_extend_backward (parser.cpp:412-441)
-    LZ_HD int extend_backward(int q0, int r0, int max_len)
+    LZ_HD int extend_backward(int q0, int r0, int max_len, bool have0 = false, u64 B0 = 0)
     {
         int maxlen = imin(max_len, imin(q0, r0));
         int last = 0;
         u64 prevB = 0;
         for (int base = 0; base < maxlen; base += 64) {
             int n = imin(64, maxlen - base);
-            u64 B = w.mism_bwd(q0 - base, r0 - base, n);
+            u64 B = (have0 && base == 0) ? B0 : w.mism_bwd(q0 - base, r0 - base, n);
             ExtMasks m = w.ext_scan(prevB, B, n);
             u64 qm = m.qual;
             if (m.brk) qm &= lowmask(ctz64(m.brk) + 1);
@@ -572,6 +584,9 @@ struct PairMachine {
             bool strk = trk && lit <= P.mqd;
             int ref_pred = r_end + lit;
             w.stamp(3);
+            int fq = 0, fr = 0;
+            u64 Bf = 0, Bb = 0;
+            bool haveF = false;
             if (strk && iabs(bpos - ref_pred) <= P.mrd) {
                 // close match: fill the gap, then the match itself (parser.cpp:630-635; quirk Q2)
                 gap_fill(i - lit, r_end, bpos + blen, lit);
@@ -585,12 +600,23 @@ struct PairMachine {
                     if (ALN) c.clear();
                     prev_rs = -1;
                 } else avail = lit;
-                int b = avail > 0 ? extend_backward(i, bpos, avail) : 0;
+                // the first chunks of the backward and of the forward extension are fetched together (one
+                // memory wait); the fold of the backward part comes out of the same mask
+                fq = i + blen; fr = bpos + blen;
+                const int nf = imax(0, imin(64, imin(D - fq, T - fr)));
+                const int nb = avail > 0 ? imax(0, imin(64, imin(avail, imin(i, bpos)))) : 0;
+                w.mism_fb(fq, fr, nf, i, bpos, nb, Bf, Bb);
+                haveF = true;
+                int b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;
                 g.finalize();                                           // a match_distant factor follows
                 region_close();
                 if (b > 0) {
                     pre_lit = avail - b;
-                    seg_range(i - b, bpos - b, b);
+                    if (b <= nb) {                                      // forward order = the b mask bits reversed
+                        const u64 M = brev64(~Bb & lowmask(b)) >> (64 - b);
+                        g.seg(M, b);
+                        if (ALN) runs(M, b, i - b, bpos - b, 0);
+                    } else seg_range(i - b, bpos - b, b);
                     prev_rs = i - b;
                 } else { pre_lit = avail; prev_rs = i; }
                 match_run(i, bpos, blen);
@@ -600,7 +626,7 @@ struct PairMachine {
             lit = 0;
             trk = true;
             w.stamp(5);
-            int e = extend_forward(i, r_end);
+            int e = extend_forward(i, r_end, haveF, Bf);
             i += e; r_end += e;
             prev_re = i;
         }
@@ -632,17 +658,6 @@ LZ_HD u64 compress_even(u64 x)        // bits 0,2,4,.. of x -> bits 0..31
 }
 LZ_HD u64 bits_below(int n) { return lowmask(n < 0 ? 0 : n); }       // bits j < n, n clamped to [0,64]
 LZ_HD u64 bits_range(int a, int b) { return bits_below(b) & ~bits_below(a); }
-LZ_HD u64 brev64(u64 x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __brevll(x);
-#else
-    u64 r = 0;
-    for (int k = 0; k < 64; ++k) r |= ((x >> k) & 1ULL) << (63 - k);
-    return r;
-#endif
-}
-
 // Anchor-style index lookup of the close seeds of one tracking step (replaces the ht_short bucket walk,
 // parser.cpp:548-580): positions p in [r_end, ref_pred + mrd) holding the step's msl-mer, ascending.
 LZ_HD void seed_lookup(const Params& P, const TextView& R, const TextView& Q, const IndexView& S,
@@ -704,6 +719,11 @@ struct LaneWave {
         if (n <= 0) return 0;
         u64 f = mism_fwd(q0 - n, r0 - n, n);                      // bit t: Q[q0-n+t]; reverse the n bits
         return brev64(f) >> (64 - n);
+    }
+    LZ_HD void mism_fb(int fq, int fr, int nf, int bq, int br, int nb, u64& Bf, u64& Bb) const
+    {
+        Bf = mism_fwd(fq, fr, nf);
+        Bb = mism_bwd(bq, br, nb);
     }
     LZ_HD ExtMasks ext_scan(u64 prevB, u64 B, int n) const
     {

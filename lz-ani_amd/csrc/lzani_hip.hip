@@ -287,6 +287,14 @@ struct DevWave {
         bool mm = lane < n && !sym_match(R, r0 - 1 - lane, Q, q0 - 1 - lane);
         return __ballot(mm);
     }
+    // both first extension chunks of a distant event: four independent loads in flight, one wait
+    __device__ __forceinline__ void mism_fb(int fq, int fr, int nf, int bq, int br, int nb, u64& Bf, u64& Bb) const
+    {
+        const bool mf = lane < nf && !sym_match(R, fr + lane, Q, fq + lane);
+        const bool mb = lane < nb && !sym_match(R, br - 1 - lane, Q, bq - 1 - lane);
+        Bf = __ballot(mf);
+        Bb = __ballot(mb);
+    }
     // Close-seed search of all tracking lanes of a round at once (replaces the ht_short bucket walk,
     // parser.cpp:548-580).  rk0/rk1 = msl-mers of the window positions r_end+lane / r_end+64+lane,
     // qk = msl-mer of this lane's step (KM_INVALID where there is none).

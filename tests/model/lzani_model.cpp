@@ -106,6 +106,11 @@ struct HostWave {
         for (int j = 0; j < n; ++j) if (!sym_match(R, r0 - 1 - j, Q, q0 - 1 - j)) m |= 1ULL << j;
         return m;
     }
+    void mism_fb(int fq, int fr, int nf, int bq, int br, int nb, u64& Bf, u64& Bb) const
+    {
+        Bf = mism_fwd(fq, fr, nf);
+        Bb = mism_bwd(bq, br, nb);
+    }
     bool find_event(int i, int n, bool trk, int r_end, int lit, int& lane, int& bpos, int& blen) const
     {
         for (int l = 0; l < n; ++l) {
