@@ -147,7 +147,11 @@ LZ_HD u64 winN(const u64* nm, int p)
     if (s == 0) return lo;
     return (lo >> s) | (nm[w + 1] << (64 - s));
 }
-LZ_HD int sym_at(const TextView& t, int p) { return (int)((t.t2[(u32)p >> 5] >> ((p & 31) * 2)) & 3ULL); }
+typedef u32 __attribute__((may_alias)) u32a;          // the packed text read as 32-bit words (16 symbols each)
+LZ_HD int sym_at(const TextView& t, int p)
+{
+    return (int)((reinterpret_cast<const u32a*>(t.t2)[(u32)p >> 4] >> ((p & 15) * 2)) & 3u);
+}
 LZ_HD int isN_at(const TextView& t, int p) { return (int)((t.nm[(u32)p >> 6] >> (p & 63)) & 1ULL); }
 
 // 1 iff both positions exist, neither is N, and the symbols are equal.  N never matches
@@ -428,7 +432,8 @@ LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool
 //                                   first step l in [0,n) whose evaluation gives len >= msl
 //   ExtMasks ext_scan(prevB, B, n)
 //   int  best_split(Lm, Rm, to_scan) argmax_s popc(Lm & low(s)) + popc(Rm >> s), last max wins
-//   void mism_fb(fq, fr, nf, bq, br, nb, Bf, Bb)   Bf = mism_fwd(fq, fr, nf), Bb = mism_bwd(bq, br, nb), one fetch
+//   void mism2(qa, ra, da, na, qb, rb, db, nb, A, B)   two mismatch masks in one fetch: bit j of A = mismatch of
+//                                   Q[qa + da*j] vs R[ra + da*j] for j < na (d = +1 forward, -1 backward), same for B
 //   void stamp(section)             profiling hook (no-op outside the LZANI_STAMPS diagnostic build)
 //   void emit_region(RegionCoords)  ALN only: one region of calc_regions (length >= reg)
 template <class W, bool ALN = false>
@@ -539,8 +544,10 @@ struct PairMachine {
         int shift = len - to_scan;
         u64 F = 0;
         if (to_scan > 0) {
-            u64 Lm = ~w.mism_fwd(ds, r_left, to_scan) & lowmask(to_scan);
-            u64 Rm = ~w.mism_fwd(ds + shift, r_right_end - to_scan, to_scan) & lowmask(to_scan);
+            u64 Lm, Rm;
+            w.mism2(ds, r_left, 1, to_scan, ds + shift, r_right_end - to_scan, 1, to_scan, Lm, Rm);
+            Lm = ~Lm & lowmask(to_scan);
+            Rm = ~Rm & lowmask(to_scan);
             int s = w.best_split(Lm, Rm, to_scan);
             u64 right = (s >= 64) ? 0ULL : ((Rm >> s) << s);
             F = (Lm & lowmask(s)) | (right << shift);
@@ -605,7 +612,7 @@ struct PairMachine {
                 fq = i + blen; fr = bpos + blen;
                 const int nf = imax(0, imin(64, imin(D - fq, T - fr)));
                 const int nb = avail > 0 ? imax(0, imin(64, imin(avail, imin(i, bpos)))) : 0;
-                w.mism_fb(fq, fr, nf, i, bpos, nb, Bf, Bb);
+                w.mism2(fq, fr, 1, nf, i - 1, bpos - 1, -1, nb, Bf, Bb);
                 haveF = true;
                 int b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;
                 g.finalize();                                           // a match_distant factor follows
@@ -720,10 +727,10 @@ struct LaneWave {
         u64 f = mism_fwd(q0 - n, r0 - n, n);                      // bit t: Q[q0-n+t]; reverse the n bits
         return brev64(f) >> (64 - n);
     }
-    LZ_HD void mism_fb(int fq, int fr, int nf, int bq, int br, int nb, u64& Bf, u64& Bb) const
+    LZ_HD void mism2(int qa, int ra, int da, int na, int qb, int rb, int db, int nb, u64& A, u64& B) const
     {
-        Bf = mism_fwd(fq, fr, nf);
-        Bb = mism_bwd(bq, br, nb);
+        A = da > 0 ? mism_fwd(qa, ra, na) : mism_bwd(qa + 1, ra + 1, na);
+        B = db > 0 ? mism_fwd(qb, rb, nb) : mism_bwd(qb + 1, rb + 1, nb);
     }
     LZ_HD ExtMasks ext_scan(u64 prevB, u64 B, int n) const
     {

@@ -277,23 +277,56 @@ struct DevWave {
     __device__ __forceinline__ void stamp(int) const {}
 #endif
 
+    // One lane's mismatch test.  N-free texts: both 32-bit text words are requested before either is
+    // used (the empty asm pins the two loads ahead of the first use - under the 64-VGPR budget the
+    // scheduler otherwise waits for the first load before it issues the second), no branch.
+    struct SymReq { u32 wr, wq; int sr, sq; bool ok; };
+    __device__ __forceinline__ SymReq sym_request(int rp, int qp) const
+    {
+        const bool vr = pos_valid(R, rp), vq = pos_valid(Q, qp);
+        const int a = vr ? rp : 0, b = vq ? qp : 0;
+        SymReq x;
+        x.wr = reinterpret_cast<const u32a*>(R.t2)[(u32)a >> 4];
+        x.wq = reinterpret_cast<const u32a*>(Q.t2)[(u32)b >> 4];
+        x.sr = (a & 15) * 2; x.sq = (b & 15) * 2; x.ok = vr & vq;
+        return x;
+    }
+    static __device__ __forceinline__ bool sym_differs(const SymReq& x)
+    {
+        return !(x.ok & ((((x.wr >> x.sr) ^ (x.wq >> x.sq)) & 3u) == 0));
+    }
+    __device__ __forceinline__ bool lane_mismatch(int rp, int qp) const
+    {
+        if (R.nfree && Q.nfree) {
+            SymReq x = sym_request(rp, qp);
+            asm volatile("" : "+v"(x.wr), "+v"(x.wq));
+            return sym_differs(x);
+        }
+        return !sym_match(R, rp, Q, qp);
+    }
     __device__ __forceinline__ u64 mism_fwd(int q0, int r0, int n) const
     {
-        bool mm = lane < n && !sym_match(R, r0 + lane, Q, q0 + lane);
-        return __ballot(mm);
+        return __ballot((lane < n) & lane_mismatch(r0 + lane, q0 + lane));
     }
     __device__ __forceinline__ u64 mism_bwd(int q0, int r0, int n) const
     {
-        bool mm = lane < n && !sym_match(R, r0 - 1 - lane, Q, q0 - 1 - lane);
-        return __ballot(mm);
+        return __ballot((lane < n) & lane_mismatch(r0 - 1 - lane, q0 - 1 - lane));
     }
-    // both first extension chunks of a distant event: four independent loads in flight, one wait
-    __device__ __forceinline__ void mism_fb(int fq, int fr, int nf, int bq, int br, int nb, u64& Bf, u64& Bb) const
+    // two masks, four independent loads in flight, one wait
+    __device__ __forceinline__ void mism2(int qa, int ra, int da, int na, int qb, int rb, int db, int nb, u64& A, u64& B) const
     {
-        const bool mf = lane < nf && !sym_match(R, fr + lane, Q, fq + lane);
-        const bool mb = lane < nb && !sym_match(R, br - 1 - lane, Q, bq - 1 - lane);
-        Bf = __ballot(mf);
-        Bb = __ballot(mb);
+        const int rpa = ra + da * lane, qpa = qa + da * lane, rpb = rb + db * lane, qpb = qb + db * lane;
+        bool ma, mb;
+        if (R.nfree && Q.nfree) {
+            SymReq x = sym_request(rpa, qpa), y = sym_request(rpb, qpb);
+            asm volatile("" : "+v"(x.wr), "+v"(x.wq), "+v"(y.wr), "+v"(y.wq));
+            ma = sym_differs(x); mb = sym_differs(y);
+        } else {
+            ma = !sym_match(R, rpa, Q, qpa);
+            mb = !sym_match(R, rpb, Q, qpb);
+        }
+        A = __ballot((lane < na) & ma);
+        B = __ballot((lane < nb) & mb);
     }
     // Close-seed search of all tracking lanes of a round at once (replaces the ht_short bucket walk,
     // parser.cpp:548-580).  rk0/rk1 = msl-mers of the window positions r_end+lane / r_end+64+lane,

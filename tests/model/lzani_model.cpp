@@ -106,10 +106,10 @@ struct HostWave {
         for (int j = 0; j < n; ++j) if (!sym_match(R, r0 - 1 - j, Q, q0 - 1 - j)) m |= 1ULL << j;
         return m;
     }
-    void mism_fb(int fq, int fr, int nf, int bq, int br, int nb, u64& Bf, u64& Bb) const
+    void mism2(int qa, int ra, int da, int na, int qb, int rb, int db, int nb, u64& A, u64& B) const
     {
-        Bf = mism_fwd(fq, fr, nf);
-        Bb = mism_bwd(bq, br, nb);
+        A = da > 0 ? mism_fwd(qa, ra, na) : mism_bwd(qa + 1, ra + 1, na);
+        B = db > 0 ? mism_fwd(qb, rb, nb) : mism_bwd(qb + 1, rb + 1, nb);
     }
     bool find_event(int i, int n, bool trk, int r_end, int lit, int& lane, int& bpos, int& blen) const
     {
