@@ -232,7 +232,8 @@ __global__ void k_idx_buckets(const u32* __restrict__ dirz, const u32* __restric
 enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS, SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5),
        SEED_LDS_WORDS = SEED_SLOTS + 256 + SEED_BM_WORDS, NQUEUES = 8 };
 
-template <bool FAST>
+// FAST: per-position k-mer words exist;  BK: the bucket table exists and its tags identify the k-mer
+template <bool FAST, bool BK = false>
 struct DevWave {
     const Params& P;
     TextView R, Q;
@@ -432,7 +433,7 @@ struct DevWave {
         const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
         const int W = nt > 0 ? imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end) : 0;
         const int tb = I.kb - I.dirbits;
-        if (!FAST || W > 128 || I.tagmask != (u32)lowmask(tb))          // the stored tag must identify the k-mer
+        if (!FAST || W > 128 || (!BK && I.tagmask != (u32)lowmask(tb))) // the stored tag must identify the k-mer
             return find_event_generic(i, n, trk, r_end, lit, ev_lane, bpos, blen);
 
         // every independent load of the round first, unconditionally (the k-mer arrays are padded by two
@@ -454,10 +455,10 @@ struct DevWave {
         //   through the directory;  no bucket table (large genomes): directory + entries.
         u32 aj = 0, ac = 0;
         uint4 bkv = {BK_EMPTY, BK_EMPTY, BK_EMPTY, BK_EMPTY};
-        bool viadir = I.bk == nullptr;
+        bool viadir = !BK && I.bk == nullptr;
         if (hq != KM_INVALID) {
             const u32 b = hq >> tb, tag = hq & I.tagmask;
-            if (I.bk) {
+            if (BK || I.bk) {
                 bkv = reinterpret_cast<const uint4*>(I.bk)[b];
                 viadir = bkv.w == BK_OVERFLOW;
                 if (!viadir)                              // BK_EMPTY never carries a real tag (tag + position bits <= 30)
@@ -582,7 +583,7 @@ __device__ __forceinline__ u32 xcc_id()
 // context holds an N (the N mask is never consulted); DEFP = the LZ parameters are the reference's
 // defaults (params.h:34-48), folded into the code as constants.
 // ALN = also emit the regions of every pair (--out-alignment).
-template <bool FAST, bool NFREE, bool DEFP, bool ALN = false>
+template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false>
 __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 {
     const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
@@ -627,12 +628,12 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
         iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
         const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
-        DevWave<FAST> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
+        DevWave<FAST, BK> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                         qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
                         lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128, lds + SEED_SLOTS + 256,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
                         FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
-        PairMachine<DevWave<FAST>, ALN> m(w, Pk, T, D);
+        PairMachine<DevWave<FAST, BK>, ALN> m(w, Pk, T, D);
         int res[3];
 #ifdef LZANI_STAMPS
         for (int k = 0; k < 8; ++k) w.acc[k] = 0;
@@ -999,6 +1000,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             } else if (rs && c->d_kmL) hipLaunchKernelGGL((k_pairs<true, false, false, true>), gd, bd, 0, c->stream, pa);
             else if (rs) hipLaunchKernelGGL((k_pairs<false, false, false, true>), gd, bd, 0, c->stream, pa);
             else if (!c->d_kmL) hipLaunchKernelGGL((k_pairs<false, false, false>), gd, bd, 0, c->stream, pa);
+            else if (c->all_nfree && defp && pa.bk) hipLaunchKernelGGL((k_pairs<true, true, true, false, true>), gd, bd, 0, c->stream, pa);
             else if (c->all_nfree && defp) hipLaunchKernelGGL((k_pairs<true, true, true>), gd, bd, 0, c->stream, pa);
             else if (c->all_nfree) hipLaunchKernelGGL((k_pairs<true, true, false>), gd, bd, 0, c->stream, pa);
             else if (defp) hipLaunchKernelGGL((k_pairs<true, false, true>), gd, bd, 0, c->stream, pa);
