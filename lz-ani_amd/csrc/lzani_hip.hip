@@ -208,8 +208,12 @@ __global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, 
 
 // Bucket table: the first four entries of every bucket side by side (16 B), so that a round reaches its
 // anchor candidates with one load after the k-mer word instead of directory + entries.
+// Tag words (tw != nullptr): the tags of those four entries in one 32-bit word, a byte 0x80|tag each, so that
+// a round DETECTS its anchor candidates from a table a quarter the size (it stays in the XCD's L2 while the
+// waves of the XCD move from one reference to the next) and only a candidate step reads the 16-byte bucket.
 __global__ void k_idx_buckets(const u32* __restrict__ dirz, const u32* __restrict__ ent, u32* __restrict__ bk,
-                              u64 dir_stride, u64 ent_stride, u64 bk_stride, u32 nb)
+                              u32* __restrict__ tw, u64 dir_stride, u64 ent_stride, u64 bk_stride, u64 tw_stride,
+                              u32 nb, int posbits)
 {
     u32 slot = blockIdx.y;
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,6 +228,15 @@ __global__ void k_idx_buckets(const u32* __restrict__ dirz, const u32* __restric
     o.w = s + 3 < e ? v[s + 3] : BK_EMPTY;
     if (e - s > 4) o.w = BK_OVERFLOW;
     reinterpret_cast<uint4*>(bk + slot * bk_stride)[b] = o;
+    if (tw) {
+        u32 w = 0;
+        if (s < e) w |= 0x80u | (o.x >> posbits);
+        if (s + 1 < e) w |= (0x80u | (o.y >> posbits)) << 8;
+        if (s + 2 < e) w |= (0x80u | (o.z >> posbits)) << 16;
+        if (s + 3 < e) w |= (0x80u | (o.w >> posbits)) << 24;
+        if (e - s > 4) w = TW_OVERFLOW;
+        tw[slot * tw_stride + b] = w;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -232,7 +245,7 @@ __global__ void k_idx_buckets(const u32* __restrict__ dirz, const u32* __restric
 enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS, SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5),
        SEED_LDS_WORDS = SEED_SLOTS + 256 + SEED_BM_WORDS, NQUEUES = 8 };
 
-// FAST: per-position k-mer words exist;  BK: the bucket table exists and its tags identify the k-mer
+// FAST: per-position k-mer words exist;  BK: the bucket table and its tag words exist
 template <bool FAST, bool BK = false>
 struct DevWave {
     const Params& P;
@@ -450,15 +463,23 @@ struct DevWave {
             rk1 = lane + 64 < W ? rk1 : KM_INVALID;
         }
         // anchor candidates of this lane's step: bucket entries carrying the step's (exact) tag.
-        //   bucket table present: one 16-byte load brings the bucket's first four entries, which stay in
-        //   registers for the verify step; a fifth+ entry (BK_OVERFLOW, ~0.03 % of buckets) sends the lane
-        //   through the directory;  no bucket table (large genomes): directory + entries.
+        //   BK: the bucket's tag word (4 B) says whether one of its first four entries carries the tag, or
+        //   that the bucket overflows (~0.03 % of buckets); the 16-byte bucket itself is read by the verify
+        //   step of a candidate only;
+        //   bucket table without tag words: one 16-byte load brings the bucket's first four entries, which stay
+        //   in registers for the verify step, an overflowing bucket sends the lane through the directory;
+        //   no bucket table (large genomes): directory + entries.
         u32 aj = 0, ac = 0;
         uint4 bkv = {BK_EMPTY, BK_EMPTY, BK_EMPTY, BK_EMPTY};
         bool viadir = !BK && I.bk == nullptr;
-        if (hq != KM_INVALID) {
+        if constexpr (BK) {
+            const bool valid = hq != KM_INVALID;
+            const u32 w = I.tw[valid ? hq >> tb : 0u];
+            const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);       // a zero byte = a slot with this tag
+            ac = (u32)(valid & ((((x - 0x01010101u) & ~x & 0x80808080u) != 0) | (w == TW_OVERFLOW)));
+        } else if (hq != KM_INVALID) {
             const u32 b = hq >> tb, tag = hq & I.tagmask;
-            if (BK || I.bk) {
+            if (I.bk) {
                 bkv = reinterpret_cast<const uint4*>(I.bk)[b];
                 viadir = bkv.w == BK_OVERFLOW;
                 if (!viadir)                              // BK_EMPTY never carries a real tag (tag + position bits <= 30)
@@ -487,7 +508,31 @@ struct DevWave {
             const int qp = i + l;
             int ap = 0, al = 0;
             const u32 cnt = __builtin_amdgcn_readlane(ac, l);
-            if (cnt) {
+            if (BK && cnt) {                                         // candidate step: now its bucket is read, by the wave
+                const u32 hql = (u32)__builtin_amdgcn_readlane((int)hq, l), tag = hql & I.tagmask;
+                const uint4 bq = reinterpret_cast<const uint4*>(I.bk)[hql >> tb];
+                const u32 en[4] = {(u32)__builtin_amdgcn_readfirstlane((int)bq.x), (u32)__builtin_amdgcn_readfirstlane((int)bq.y),
+                                   (u32)__builtin_amdgcn_readfirstlane((int)bq.z), (u32)__builtin_amdgcn_readfirstlane((int)bq.w)};
+                if (en[3] == BK_OVERFLOW) {                          // the whole bucket, ascending position
+                    u32 s = I.dirz[hql >> tb], e = I.dirz[(hql >> tb) + 1];
+                    if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
+                    for (u32 j = s; j < e; ++j) {
+                        const u32 x = (u32)__builtin_amdgcn_readfirstlane((int)I.ent[j]);
+                        if ((x >> I.posbits) != tag) continue;
+                        const int p = (int)(x & pm);
+                        const int m = wave_equal_len(p, qp, 0);
+                        if (m >= P.mal && m > al) { al = m; ap = p; }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if ((en[k] >> I.posbits) != tag) continue;
+                        const int p = (int)(en[k] & pm);
+                        const int m = wave_equal_len(p, qp, 0);
+                        if (m >= P.mal && m > al) { al = m; ap = p; }
+                    }
+                }
+            } else if (cnt) {
                 if (__builtin_amdgcn_readlane((int)viadir, l)) {
                     const u32 j0 = __builtin_amdgcn_readlane(aj, l);
                     for (u32 k = 0; k < cnt; ++k) {                  // same k-mer, ascending position
@@ -555,6 +600,8 @@ struct PairArgs {
     u64 dir_stride, ent_stride;
     const u32* bk;           // bucket tables (4 entries per bucket) or nullptr
     u64 bk_stride;
+    const u32* tw;           // tag words (one per bucket) or nullptr
+    u64 tw_stride;
     const u32* ref_ids;      // device, batch-relative rows
     const u64* row_off;      // device, batch-relative rows (+1), absolute pair offsets
     const u32* query_ids;    // device, absolute pair offsets, or nullptr for dense rows
@@ -627,6 +674,7 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         iv.ent = a.ent + slot * a.ent_stride;
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
         iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
+        iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
         const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
         DevWave<FAST, BK> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                         qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
@@ -697,6 +745,7 @@ __global__ void __launch_bounds__(256) k_pairs_tpp(TppArgs ta)
         iv.ent = a.ent + slot * a.ent_stride;
         iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
         iv.bk = nullptr; sv.bk = nullptr;
+        iv.tw = nullptr; sv.tw = nullptr;
         sv.dirz = ta.sdirz + slot * ta.sdir_stride;
         sv.ent = ta.sent + slot * ta.sent_stride;
         sv.kb = ta.sgeo.kb; sv.dirbits = ta.sgeo.dirbits; sv.posbits = ta.sgeo.posbits; sv.tagmask = ta.sgeo.tagmask;
@@ -746,6 +795,8 @@ struct lzani_ctx {
     u32* d_ent = nullptr;
     u32* d_bk = nullptr;          // bucket tables (viral-size directories only)
     u64 bk_stride = 0;
+    u32* d_tw = nullptr;          // tag words of the bucket tables (tag bits <= 6)
+    u64 tw_stride = 0;
     u32* d_sdirz = nullptr;       // seed (msl) index slabs, thread-per-pair kernel only
     u32* d_sent = nullptr;
     u64 sdir_stride = 0;
@@ -803,8 +854,8 @@ void free_genomes(lzani_ctx* c)
 }
 void free_slabs(lzani_ctx* c)
 {
-    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_sdirz); hipFree(c->d_sent); hipFree(c->d_bk);
-    c->d_dirz = c->d_ent = c->d_sdirz = c->d_sent = c->d_bk = nullptr; c->slots = 0;
+    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_sdirz); hipFree(c->d_sent); hipFree(c->d_bk); hipFree(c->d_tw);
+    c->d_dirz = c->d_ent = c->d_sdirz = c->d_sent = c->d_bk = c->d_tw = nullptr; c->slots = 0;
 }
 
 int ensure_slabs(lzani_ctx* c, u32 want_rows)
@@ -823,8 +874,10 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
         const char* e = getenv("LZANI_NO_BUCKETS");
         c->bk_stride = (c->d_kmL && exact && c->geo.dirbits <= 18 && tagbits + c->geo.posbits <= 30 && !(e && *e == '1'))
                            ? ((u64)4 << c->geo.dirbits) : 0;
+        const char* t = getenv("LZANI_NO_TAGWORDS");
+        c->tw_stride = (c->bk_stride && tagbits <= 6 && !(t && *t == '1')) ? ((u64)1 << c->geo.dirbits) : 0;
     }
-    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + (c->use_tpp ? c->sdir_stride + c->ent_stride : 0));
+    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + (c->use_tpp ? c->sdir_stride + c->ent_stride : 0));
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     size_t have = c->slots * per_slot;
@@ -835,6 +888,7 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     HIPCHK(c, hipMalloc(&c->d_dirz, (size_t)slots * c->dir_stride * 4));
     HIPCHK(c, hipMalloc(&c->d_ent, (size_t)slots * c->ent_stride * 4));
     if (c->bk_stride) HIPCHK(c, hipMalloc(&c->d_bk, (size_t)slots * c->bk_stride * 4));
+    if (c->tw_stride) HIPCHK(c, hipMalloc(&c->d_tw, (size_t)slots * c->tw_stride * 4));
     if (c->use_tpp) {
         HIPCHK(c, hipMalloc(&c->d_sdirz, (size_t)slots * c->sdir_stride * 4));
         HIPCHK(c, hipMalloc(&c->d_sent, (size_t)slots * c->ent_stride * 4));
@@ -875,7 +929,8 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
                        c->d_dirz, c->d_ent, c->dir_stride, c->ent_stride, nb);
     if (c->d_bk)
         hipLaunchKernelGGL(k_idx_buckets, dim3((nb + 255) / 256, rows), dim3(256), 0, c->stream,
-                           c->d_dirz, c->d_ent, c->d_bk, c->dir_stride, c->ent_stride, c->bk_stride, nb);
+                           c->d_dirz, c->d_ent, c->d_bk, c->d_tw, c->dir_stride, c->ent_stride, c->bk_stride, c->tw_stride,
+                           nb, c->geo.posbits);
     if (c->use_tpp) {                             // second index over the msl-mers
         IdxArgs sa = ia;
         sa.dirz = c->d_sdirz; sa.ent = c->d_sent; sa.dir_stride = c->sdir_stride;
@@ -954,6 +1009,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.dirz = c->d_dirz; pa.ent = c->d_ent;
             pa.dir_stride = c->dir_stride; pa.ent_stride = c->ent_stride;
             pa.bk = c->d_bk; pa.bk_stride = c->bk_stride;
+            pa.tw = c->d_tw; pa.tw_stride = c->tw_stride;
             pa.ref_ids = d_ref + k0; pa.row_off = d_off + k0; pa.query_ids = d_q;
             pa.out = d_out; pa.cursor = c->d_cursor;
             // rows -> queues: longest row first onto the least loaded queue (equal rows: round robin)
@@ -1000,7 +1056,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             } else if (rs && c->d_kmL) hipLaunchKernelGGL((k_pairs<true, false, false, true>), gd, bd, 0, c->stream, pa);
             else if (rs) hipLaunchKernelGGL((k_pairs<false, false, false, true>), gd, bd, 0, c->stream, pa);
             else if (!c->d_kmL) hipLaunchKernelGGL((k_pairs<false, false, false>), gd, bd, 0, c->stream, pa);
-            else if (c->all_nfree && defp && pa.bk) hipLaunchKernelGGL((k_pairs<true, true, true, false, true>), gd, bd, 0, c->stream, pa);
+            else if (c->all_nfree && defp && pa.tw) hipLaunchKernelGGL((k_pairs<true, true, true, false, true>), gd, bd, 0, c->stream, pa);
             else if (c->all_nfree && defp) hipLaunchKernelGGL((k_pairs<true, true, true>), gd, bd, 0, c->stream, pa);
             else if (c->all_nfree) hipLaunchKernelGGL((k_pairs<true, true, false>), gd, bd, 0, c->stream, pa);
             else if (defp) hipLaunchKernelGGL((k_pairs<true, false, true>), gd, bd, 0, c->stream, pa);
