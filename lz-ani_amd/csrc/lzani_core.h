@@ -85,10 +85,11 @@ struct IndexView {        // anchor index of one reference (all mal-mers of R)
     u32 tagmask;          // stored tag bits
     const u32* bk;        // optional bucket table: 4 entries per bucket (BK_EMPTY padded; entry 3 = BK_OVERFLOW
                           // when the bucket holds more than four), or nullptr
-    const u32* tw;        // optional tag words (tag bits <= 6): per bucket one byte 0x80|tag per entry of the bucket
-                          // table, 0 for an empty slot; TW_OVERFLOW for a bucket of more than four
+    const u32* tw;        // optional tag words (tag bits <= 7): per bucket one byte 0x80|tag per entry of the bucket
+                          // table (slot k in byte k), 0 for an empty slot; TW_OVERFLOW for a bucket of more than
+                          // four (no bucket looks like it: the tags of a bucket ascend with the slot)
 };
-enum : u32 { BK_EMPTY = 0xFFFFFFFFu, BK_OVERFLOW = 0xFFFFFFFEu, TW_OVERFLOW = 0xFFFFFFFFu };
+enum : u32 { BK_EMPTY = 0xFFFFFFFFu, BK_OVERFLOW = 0xFFFFFFFEu, TW_OVERFLOW = 0x808080FFu };
 
 // ---- bit helpers --------------------------------------------------------------------
 LZ_HD u64 lowmask(int n) { return n >= 64 ? ~0ULL : (n <= 0 ? 0ULL : ((1ULL << n) - 1ULL)); }

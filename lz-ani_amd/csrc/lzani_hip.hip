@@ -795,7 +795,7 @@ struct lzani_ctx {
     u32* d_ent = nullptr;
     u32* d_bk = nullptr;          // bucket tables (viral-size directories only)
     u64 bk_stride = 0;
-    u32* d_tw = nullptr;          // tag words of the bucket tables (tag bits <= 6)
+    u32* d_tw = nullptr;          // tag words of the bucket tables (tag bits <= 7)
     u64 tw_stride = 0;
     u32* d_sdirz = nullptr;       // seed (msl) index slabs, thread-per-pair kernel only
     u32* d_sent = nullptr;
@@ -875,7 +875,7 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
         c->bk_stride = (c->d_kmL && exact && c->geo.dirbits <= 18 && tagbits + c->geo.posbits <= 30 && !(e && *e == '1'))
                            ? ((u64)4 << c->geo.dirbits) : 0;
         const char* t = getenv("LZANI_NO_TAGWORDS");
-        c->tw_stride = (c->bk_stride && tagbits <= 6 && !(t && *t == '1')) ? ((u64)1 << c->geo.dirbits) : 0;
+        c->tw_stride = (c->bk_stride && tagbits <= 7 && !(t && *t == '1')) ? ((u64)1 << c->geo.dirbits) : 0;
     }
     size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + (c->use_tpp ? c->sdir_stride + c->ent_stride : 0));
     size_t free_b = 0, total_b = 0;
@@ -1053,14 +1053,27 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (c->all_nfree) hipLaunchKernelGGL((k_pairs_tpp<true, false>), tg, bd, 0, c->stream, ta);
                 else if (defp) hipLaunchKernelGGL((k_pairs_tpp<false, true>), tg, bd, 0, c->stream, ta);
                 else hipLaunchKernelGGL((k_pairs_tpp<false, false>), tg, bd, 0, c->stream, ta);
-            } else if (rs && c->d_kmL) hipLaunchKernelGGL((k_pairs<true, false, false, true>), gd, bd, 0, c->stream, pa);
-            else if (rs) hipLaunchKernelGGL((k_pairs<false, false, false, true>), gd, bd, 0, c->stream, pa);
-            else if (!c->d_kmL) hipLaunchKernelGGL((k_pairs<false, false, false>), gd, bd, 0, c->stream, pa);
-            else if (c->all_nfree && defp && pa.tw) hipLaunchKernelGGL((k_pairs<true, true, true, false, true>), gd, bd, 0, c->stream, pa);
-            else if (c->all_nfree && defp) hipLaunchKernelGGL((k_pairs<true, true, true>), gd, bd, 0, c->stream, pa);
-            else if (c->all_nfree) hipLaunchKernelGGL((k_pairs<true, true, false>), gd, bd, 0, c->stream, pa);
-            else if (defp) hipLaunchKernelGGL((k_pairs<true, false, true>), gd, bd, 0, c->stream, pa);
-            else hipLaunchKernelGGL((k_pairs<true, false, false>), gd, bd, 0, c->stream, pa);
+            } else {
+#define LZ_PAIRS(F, N, D, A, B) hipLaunchKernelGGL((k_pairs<F, N, D, A, B>), gd, bd, 0, c->stream, pa)
+                const bool fast = c->d_kmL != nullptr, tw = pa.tw != nullptr, nf = c->all_nfree;
+                if (rs) {                                   // alignment output: one generic instantiation per index form
+                    if (!fast) LZ_PAIRS(false, false, false, true, false);
+                    else if (tw) LZ_PAIRS(true, false, false, true, true);
+                    else LZ_PAIRS(true, false, false, true, false);
+                } else if (!fast) LZ_PAIRS(false, false, false, false, false);
+                else if (tw) {
+                    if (nf && defp) LZ_PAIRS(true, true, true, false, true);
+                    else if (nf) LZ_PAIRS(true, true, false, false, true);
+                    else if (defp) LZ_PAIRS(true, false, true, false, true);
+                    else LZ_PAIRS(true, false, false, false, true);
+                } else {
+                    if (nf && defp) LZ_PAIRS(true, true, true, false, false);
+                    else if (nf) LZ_PAIRS(true, true, false, false, false);
+                    else if (defp) LZ_PAIRS(true, false, true, false, false);
+                    else LZ_PAIRS(true, false, false, false, false);
+                }
+#undef LZ_PAIRS
+            }
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
             c->tm.pair_launches += 1;

@@ -272,6 +272,39 @@ def test_mixed_n_content_and_parameter_instantiations():
             assert len(bad) == 0, (name, prm, bad[:3].tolist())
 
 
+@pytest.mark.parametrize("env", [{}, {"LZANI_NO_TAGWORDS": "1"}, {"LZANI_NO_BUCKETS": "1"}], ids=["tagwords", "buckets", "directory"])
+def test_index_forms(monkeypatch, env):
+    """The three forms of the anchor index the pair kernel can read (tag words + bucket table, bucket table
+    alone, directory + entries) give the same results: genomes with and without N, default and other
+    parameters, and the alignment instantiation."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _, seqs = SG.make_set(20, 11, lmin=17000, lmax=20000, fam=5)
+    seqs[3] = np.concatenate([seqs[3][:4000], np.full(30, 5, np.uint8), seqs[3][4000:]])
+    for data in (seqs, seqs[4:12]):                            # with the N genome / N-free
+        for prm in (None, dict(reg=30, aw=20)):
+            got = gpu_all2all(data, prm)
+            want = O.oracle_all2all(data, prm, threads=16)
+            assert np.array_equal(got, want), (env, prm)
+    eng = L.Engine()
+    eng.set_genomes(seqs[:8])
+    ref_ids, row_off = L.dense_rows(8)
+    out, regs = eng.run_rows_regions(ref_ids, row_off, None)
+    eng.close()
+    assert np.array_equal(out.reshape(-1, 3), O.oracle_all2all(seqs[:8], None, threads=16)[~np.eye(8, dtype=bool)])
+    cols = ("ref_start", "ref_end", "seq_start", "seq_end", "num_matches", "num_mismatches")
+    e = 0
+    for r in range(8):
+        for q in range(8):
+            if q == r:
+                continue
+            mine = regs[regs["pair"] == e]
+            _, want = O.oracle_pair(seqs[r], seqs[q], None, want_regions=True)
+            got = np.stack([mine[k] for k in cols], axis=1) if len(mine) else np.zeros((0, 6), np.int32)
+            assert np.array_equal(got, want), (env, r, q)
+            e += 1
+
+
 def test_thread_per_pair_variant(monkeypatch):
     """The opt-in thread-per-pair kernel (LZANI_KERNEL=tpp; slower, kept for experiments) is bit-exact too."""
     monkeypatch.setenv("LZANI_KERNEL", "tpp")
