@@ -17,7 +17,7 @@
 //   * approximate extension consumes 64 symbols per step from a sliding 128-bit mismatch
 //     window instead of a circular flag buffer.
 //
-// The file is shared by the HIP kernels (wave = 64 lanes, lzani_hip.hip) and by the host-side
+// The file is shared by the HIP kernels (wave = 64 lanes, lzani_kernels_pairs.h) and by the host-side
 // models used only by the tests (tests/model/): the state machine (PairMachine) is templated on a
 // `Wave` policy that supplies the cross-lane primitives -- DevWave on the device (ballots, LDS),
 // a lane-emulating policy and the lane-serial LaneWave on the host.
@@ -345,7 +345,7 @@ LZ_HD void seed_search_window(const Params& P, const TextView& R, const TextView
 //   r_end : reference end of the last match (= ref_pred - lit)
 //   lit   : literal run length at the start of this step
 // The HIP wave replaces the per-lane window scan by a shared LDS join with the same candidate
-// order (lzani_hip.hip, DevWave::find_event).
+// order (lzani_kernels_pairs.h, DevWave::find_event).
 LZ_HD void eval_step(const Params& P, const TextView& R, const TextView& Q, const IndexView& I,
                      int qp, bool trk, int r_end, int lit, int& bp, int& bl)
 {

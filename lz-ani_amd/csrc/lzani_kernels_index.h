@@ -1,0 +1,218 @@
+// lzani_kernels_index.h -- device kernels that prepare the genomes and the per-reference anchor index.
+// Included by lzani_hip.hip only (after lzani_core.h / lzani_layout.h).
+//   k_pack        reservoir codes -> packed reference text  fwd | N^2mrd | RC | N^mrd
+//                 (replaces seq_view::unpack + CParser::append/append_rc, parser.h:57-96)
+//   k_kmers       per-genome k-mer words: mixed mal-mer hash and msl-mer of every text position
+//                 (replaces the per-pair prepare_kmers of prepare_data, parser.cpp:46-47)
+//   k_idx_count / k_idx_scan / k_idx_fill / k_idx_sort / k_idx_buckets
+//                 per-reference anchor index of all mal-mers (replaces prepare_kmers +
+//                 prepare_ht_long, parser.cpp:53-103, 146-189): bucket directory + (tag|pos)
+//                 entries, ascending inside a bucket; bucket table and tag words for viral sizes
+#pragma once
+
+namespace lzani {
+
+struct GenomeTab {
+    const u64* t2;       // all packed texts, concatenated
+    const u64* nm;       // all N masks, concatenated
+    const u64* nmoff;    // per genome: word offset into nm (t2 offset is twice that, k-mer arrays 64x)
+    const int* L;        // per genome: sequence length
+    const u32* kmL;      // per text position: mix_key(mal-mer) or KM_INVALID   (fast path: mal, msl <= 15)
+    const u32* kmS;      // per text position: msl-mer or KM_INVALID
+    const int* hasN;     // per genome: 1 if the sequence holds a non-ACGT symbol
+};
+
+enum : u32 { KM_INVALID = 0xFFFFFFFFu };
+
+// k_kmers: one thread per text position of every genome: the two k-mer words the pair kernel and
+// the index build read instead of re-extracting k-mers (the reference recomputes them per pair,
+// parser.cpp:46-47; here once per genome and run).
+__global__ void k_kmers(GenomeTab G, u32* __restrict__ kmL, u32* __restrict__ kmS, int mal, int msl, int mrd, int Tmax)
+{
+    u32 g = blockIdx.y;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int T = ref_text_len(G.L[g], mrd);
+    if (p >= Tmax || p >= T) return;
+    u64 o = G.nmoff[g];
+    TextView R = ref_view(G.t2 + 2 * o, G.nm + o, G.L[g], mrd, false);
+    u64 key;
+    u32 a = KM_INVALID, b = KM_INVALID;
+    if (kmer_at(R, p, mal, key)) a = (u32)mix_key(key, 2 * mal);
+    if (kmer_at(R, p, msl, key)) b = (u32)key;
+    kmL[64 * o + p] = a;
+    kmS[64 * o + p] = b;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pack: one thread per 64-symbol block of a reference text.
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack(const uint8_t* __restrict__ codes, const u64* __restrict__ codeoff,
+                       u64* __restrict__ t2, u64* __restrict__ nm, const u64* __restrict__ nmoff,
+                       const int* __restrict__ Ls, int* __restrict__ hasN, int mrd, u32 n)
+{
+    u32 g = blockIdx.y;
+    if (g >= n) return;
+    int L = Ls[g];
+    int T = ref_text_len(L, mrd);
+    size_t nblk = text_wordsN(T);
+    size_t blk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nblk) return;
+    const uint8_t* c = codes + codeoff[g];
+    u64 w0 = 0, w1 = 0, nw = 0;
+    int rc0 = L + 2 * mrd;
+    for (int j = 0; j < 64; ++j) {
+        long p = (long)blk * 64 + j;
+        int s = 4;
+        if (p < L) { int v = c[p]; s = v < 4 ? v : 4; if (v >= 4) hasN[g] = 1; }
+        else if (p >= rc0 && p < rc0 + L) { int v = c[L - 1 - (p - rc0)]; s = v < 4 ? 3 - v : 4; }
+        if (s < 4) {
+            if (j < 32) w0 |= (u64)s << (2 * j);
+            else w1 |= (u64)s << (2 * (j - 32));
+        } else nw |= 1ULL << j;
+    }
+    size_t o = nmoff[g] + blk;
+    nm[o] = nw;
+    t2[2 * o] = w0;
+    t2[2 * o + 1] = w1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Anchor index build.  Slot s of the batch holds the index of reference ref_ids[s].
+// ------------------------------------------------------------------------------------------
+struct IdxArgs {
+    GenomeTab G;
+    const u32* ref_ids;      // device, batch-relative
+    u32* dirz;               // slots * dir_stride
+    u32* ent;                // slots * ent_stride
+    u64 dir_stride, ent_stride;
+    int mal, mrd;            // mal = the k of this index (min_anchor_len, or min_seed_len for the seed index)
+    IndexGeom geo;
+    int seed;                // 1: index of the msl-mers (key words from kmS, mixed here)
+};
+
+__device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, u32& bucket, u32& entry)
+{
+    u32 g = a.ref_ids[slot];
+    int T = ref_text_len(a.G.L[g], a.mrd);
+    if (p + a.mal > T) return false;
+    u64 o = a.G.nmoff[g];
+    u64 h;
+    if (a.G.kmL) {
+        u32 v = a.seed ? a.G.kmS[64 * o + p] : a.G.kmL[64 * o + p];
+        if (v == KM_INVALID) return false;
+        h = a.seed ? mix_key(v, a.geo.kb) : (u64)v;
+    } else {
+        TextView R = ref_view(a.G.t2 + 2 * o, a.G.nm + o, a.G.L[g], a.mrd, false);
+        u64 key;
+        if (!kmer_at(R, p, a.mal, key)) return false;
+        h = mix_key(key, a.geo.kb);
+    }
+    int tb = a.geo.kb - a.geo.dirbits;
+    bucket = (u32)(h >> tb);
+    u32 tag = (u32)(h & lowmask(tb)) & a.geo.tagmask;
+    entry = (tag << a.geo.posbits) | (u32)p;
+    return true;
+}
+
+__global__ void k_idx_count(IdxArgs a, int Tmax)
+{
+    u32 slot = blockIdx.y;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Tmax) return;
+    u32 b, e;
+    if (idx_slot_key(a, slot, p, b, e)) atomicAdd(&a.dirz[slot * a.dir_stride + 1 + b], 1u);
+}
+
+// In-place exclusive scan of the 2^dirbits bucket counts of one slot (one 1024-thread block).
+__global__ void __launch_bounds__(1024) k_idx_scan(u32* dirz, u64 dir_stride, u32 nb)
+{
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry_s;
+    u32* cnt = dirz + (u64)blockIdx.x * dir_stride + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 base = 0; base < nb; base += 1024) {
+        u32 idx = base + threadIdx.x;
+        u32 v = idx < nb ? cnt[idx] : 0;
+        u32 x = v;                                   // inclusive scan inside the wave
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        u32 woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        u32 carry = carry_s;
+        if (idx < nb) cnt[idx] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+}
+
+__global__ void k_idx_fill(IdxArgs a, int Tmax)
+{
+    u32 slot = blockIdx.y;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Tmax) return;
+    u32 b, e;
+    if (idx_slot_key(a, slot, p, b, e)) {
+        u32 at = atomicAdd(&a.dirz[slot * a.dir_stride + 1 + b], 1u);
+        a.ent[slot * a.ent_stride + at] = e;
+    }
+}
+
+// Ascending order inside every bucket (candidate order = ascending reference position per
+// k-mer, the order of the reference's probe chain).  Buckets hold ~1 entry.
+__global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, u32 nb)
+{
+    u32 slot = blockIdx.y;
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const u32* d = dirz + slot * dir_stride;
+    u32 s = d[b], e = d[b + 1];
+    u32* v = ent + slot * ent_stride;
+    for (u32 i = s + 1; i < e; ++i) {
+        u32 x = v[i];
+        u32 j = i;
+        while (j > s && v[j - 1] > x) { v[j] = v[j - 1]; --j; }
+        v[j] = x;
+    }
+}
+
+// Bucket table: the first four entries of every bucket side by side (16 B), so that a round reaches its
+// anchor candidates with one load after the k-mer word instead of directory + entries.
+// Tag words (tw != nullptr): the tags of those four entries in one 32-bit word, a byte 0x80|tag each, so that
+// a round DETECTS its anchor candidates from a table a quarter the size (it stays in the XCD's L2 while the
+// waves of the XCD move from one reference to the next) and only a candidate step reads the 16-byte bucket.
+__global__ void k_idx_buckets(const u32* __restrict__ dirz, const u32* __restrict__ ent, u32* __restrict__ bk,
+                              u32* __restrict__ tw, u64 dir_stride, u64 ent_stride, u64 bk_stride, u64 tw_stride,
+                              u32 nb, int posbits)
+{
+    u32 slot = blockIdx.y;
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const u32* d = dirz + slot * dir_stride;
+    const u32* v = ent + slot * ent_stride;
+    const u32 s = d[b], e = d[b + 1];
+    uint4 o;
+    o.x = s < e ? v[s] : BK_EMPTY;
+    o.y = s + 1 < e ? v[s + 1] : BK_EMPTY;
+    o.z = s + 2 < e ? v[s + 2] : BK_EMPTY;
+    o.w = s + 3 < e ? v[s + 3] : BK_EMPTY;
+    if (e - s > 4) o.w = BK_OVERFLOW;
+    reinterpret_cast<uint4*>(bk + slot * bk_stride)[b] = o;
+    if (tw) {
+        u32 w = 0;
+        if (s < e) w |= 0x80u | (o.x >> posbits);
+        if (s + 1 < e) w |= (0x80u | (o.y >> posbits)) << 8;
+        if (s + 2 < e) w |= (0x80u | (o.z >> posbits)) << 16;
+        if (s + 3 < e) w |= (0x80u | (o.w >> posbits)) << 24;
+        if (e - s > 4) w = TW_OVERFLOW;
+        tw[slot * tw_stride + b] = w;
+    }
+}
+
+}  // namespace lzani

@@ -1,0 +1,534 @@
+// lzani_kernels_pairs.h -- the pair kernels.  Included by lzani_hip.hip only (after lzani_kernels_index.h).
+//   DevWave       the wave policy of PairMachine (lzani_core.h) on the device: one wavefront per pair
+//   k_pairs       one wavefront per directed genome pair, persistent waves pulling pairs from
+//                 per-XCD work queues (replaces prepare_data + parse + calc_stats,
+//                 parser.cpp:37-50, 482-716, 734-783, and the worker loop of do_matching,
+//                 lz_matcher.cpp:192-269); instantiations FAST/NFREE/DEFP/ALN/BK, see the kernel
+//   k_pairs_tpp   thread-per-pair variant of the same machine (opt-in, LZANI_KERNEL=tpp; slower)
+#pragma once
+
+namespace lzani {
+
+// ------------------------------------------------------------------------------------------
+// k_pairs: the pair kernel.
+// ------------------------------------------------------------------------------------------
+enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS, SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5),
+       SEED_LDS_WORDS = SEED_SLOTS + 256 + SEED_BM_WORDS, NQUEUES = 8 };
+
+// FAST: per-position k-mer words exist;  BK: the bucket table and its tag words exist
+template <bool FAST, bool BK = false>
+struct DevWave {
+    const Params& P;
+    TextView R, Q;
+    IndexView I;
+    int lane;
+    u32* heads;      // per-wave LDS: SEED_SLOTS chain heads
+    u32* nexts;      // 128 chain links
+    u32* keys;       // 128 window msl-mers
+    u32* bitmap;     // SEED_BM_WORDS words, all zero between rounds
+    const u32* rkS;  // FAST: msl-mers of the reference text, one per position
+    const u32* qkL;  // FAST: hashed mal-mers of the query text
+    const u32* qkS;  // FAST: msl-mers of the query text
+    // alignment instantiation: region sink
+    lzani_region* reg_out;
+    unsigned long long* reg_count;
+    unsigned long long reg_cap, pair_e;
+    __device__ __forceinline__ void emit_region(const RegionCoords& c) const
+    {
+        // one slot per wave without a lane-dependent branch (see the note at the ticket fetch)
+        const unsigned long long old = atomicAdd(reg_count, lane == 0 ? 1ULL : 0ULL);
+        const u32 lo = __builtin_amdgcn_readfirstlane((u32)old), hi = __builtin_amdgcn_readfirstlane((u32)(old >> 32));
+        const unsigned long long slot = ((unsigned long long)hi << 32) | lo;
+        if (slot < reg_cap) {
+            lzani_region* o = reg_out + slot;
+            o->pair = pair_e;
+            o->ref_start = c.ref_start; o->ref_end = c.ref_end; o->seq_start = c.seq_start; o->seq_end = c.seq_end;
+            o->num_matches = c.nm; o->num_mismatches = c.nmm;
+        }
+    }
+#ifdef LZANI_STAMPS
+    // diagnostic build only: cycles per section, summed per wave, added to g_stamp_acc at pair end
+    mutable unsigned long long t0;
+    mutable unsigned long long acc[8];
+    mutable int cur;
+    __device__ __forceinline__ void stamp(int k) const
+    {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        acc[cur] += t - t0; cur = k; t0 = t;
+    }
+#else
+    __device__ __forceinline__ void stamp(int) const {}
+#endif
+
+    // One lane's mismatch test.  N-free texts: both 32-bit text words are requested before either is
+    // used (the empty asm pins the two loads ahead of the first use - under the 64-VGPR budget the
+    // scheduler otherwise waits for the first load before it issues the second), no branch.
+    struct SymReq { u32 wr, wq; int sr, sq; bool ok; };
+    __device__ __forceinline__ SymReq sym_request(int rp, int qp) const
+    {
+        const bool vr = pos_valid(R, rp), vq = pos_valid(Q, qp);
+        const int a = vr ? rp : 0, b = vq ? qp : 0;
+        SymReq x;
+        x.wr = reinterpret_cast<const u32a*>(R.t2)[(u32)a >> 4];
+        x.wq = reinterpret_cast<const u32a*>(Q.t2)[(u32)b >> 4];
+        x.sr = (a & 15) * 2; x.sq = (b & 15) * 2; x.ok = vr & vq;
+        return x;
+    }
+    static __device__ __forceinline__ bool sym_differs(const SymReq& x)
+    {
+        return !(x.ok & ((((x.wr >> x.sr) ^ (x.wq >> x.sq)) & 3u) == 0));
+    }
+    __device__ __forceinline__ bool lane_mismatch(int rp, int qp) const
+    {
+        if (R.nfree && Q.nfree) {
+            SymReq x = sym_request(rp, qp);
+            asm volatile("" : "+v"(x.wr), "+v"(x.wq));
+            return sym_differs(x);
+        }
+        return !sym_match(R, rp, Q, qp);
+    }
+    __device__ __forceinline__ u64 mism_fwd(int q0, int r0, int n) const
+    {
+        return __ballot((lane < n) & lane_mismatch(r0 + lane, q0 + lane));
+    }
+    __device__ __forceinline__ u64 mism_bwd(int q0, int r0, int n) const
+    {
+        return __ballot((lane < n) & lane_mismatch(r0 - 1 - lane, q0 - 1 - lane));
+    }
+    // two masks, four independent loads in flight, one wait
+    __device__ __forceinline__ void mism2(int qa, int ra, int da, int na, int qb, int rb, int db, int nb, u64& A, u64& B) const
+    {
+        const int rpa = ra + da * lane, qpa = qa + da * lane, rpb = rb + db * lane, qpb = qb + db * lane;
+        bool ma, mb;
+        if (R.nfree && Q.nfree) {
+            SymReq x = sym_request(rpa, qpa), y = sym_request(rpb, qpb);
+            asm volatile("" : "+v"(x.wr), "+v"(x.wq), "+v"(y.wr), "+v"(y.wq));
+            ma = sym_differs(x); mb = sym_differs(y);
+        } else {
+            ma = !sym_match(R, rpa, Q, qpa);
+            mb = !sym_match(R, rpb, Q, qpb);
+        }
+        A = __ballot((lane < na) & ma);
+        B = __ballot((lane < nb) & mb);
+    }
+    // Close-seed search of all tracking lanes of a round at once (replaces the ht_short bucket walk,
+    // parser.cpp:548-580).  rk0/rk1 = msl-mers of the window positions r_end+lane / r_end+64+lane,
+    // qk = msl-mer of this lane's step (KM_INVALID where there is none).
+    //  1. prefilter: the window k-mers set bits in a per-wave 16 Kbit LDS bitmap (exact for msl <= 7,
+    //     a Bloom filter above), each tracking lane tests its own k-mer; in four rounds out of five no
+    //     lane hits and the search ends here (the bits are cleared again, the bitmap is always zero
+    //     between rounds);
+    //  2. otherwise the window k-mers are chained into a small LDS hash table and every hit lane
+    //     walks the chain of its k-mer, collecting the matching positions below its own window limit
+    //     into a 128-bit mask; candidates are then taken in ascending position, the order of the
+    //     reference's bucket.
+    __device__ __forceinline__ u32 bm_hash(u32 k) const
+    {
+        return P.msl <= 7 ? k : (k * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
+    }
+    __device__ __forceinline__ void seed_join(int lit, u32 rk0, u32 rk1, u32 qk, u64& c0, u64& c1) const
+    {
+        c0 = 0; c1 = 0;
+        const u32 EMPTY = 0xFFFFFFFFu;
+        const u32 b0 = bm_hash(rk0), b1 = bm_hash(rk1), bq = bm_hash(qk);
+        if (rk0 != KM_INVALID) atomicOr(&bitmap[b0 >> 5], 1u << (b0 & 31));
+        if (rk1 != KM_INVALID) atomicOr(&bitmap[b1 >> 5], 1u << (b1 & 31));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool hit = false;
+        if (qk != KM_INVALID) hit = (bitmap[bq >> 5] >> (bq & 31)) & 1u;
+        const u64 any = __ballot(hit);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (rk0 != KM_INVALID) bitmap[b0 >> 5] = 0;
+        if (rk1 != KM_INVALID) bitmap[b1 >> 5] = 0;
+        if (!any) return;
+
+        for (int k = 0; k < SEED_SLOTS / 64; ++k) heads[lane + 64 * k] = EMPTY;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (rk0 != KM_INVALID) {
+            keys[lane] = rk0;
+            nexts[lane] = atomicExch(&heads[(rk0 * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)], (u32)lane);
+        }
+        if (rk1 != KM_INVALID) {
+            keys[lane + 64] = rk1;
+            nexts[lane + 64] = atomicExch(&heads[(rk1 * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)], (u32)lane + 64);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (hit) {
+            const u32 lim = (u32)(lit + lane + P.mrd);          // this step's window is [0, lim)
+            int guard = 0;
+            for (u32 h = heads[(qk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)]; h != EMPTY; h = nexts[h]) {
+                if (++guard > 128) { LZ_GUARD_TRIP(4); break; }
+                const u64 bit = (u64)(keys[h] == qk && h < lim) << (h & 63);
+                c0 |= h < 64 ? bit : 0;
+                c1 |= h < 64 ? 0 : bit;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    __device__ __forceinline__ u64 bcast64(u64 v, int l) const      // readlane returns a signed int: widen as u32
+    {
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+        return ((u64)hi << 32) | lo;
+    }
+    // equal_len by the whole wave: 64 symbols per step (ballot + ctz), same value as lzani::equal_len
+    __device__ __forceinline__ int wave_equal_len(int rp, int qp, int start) const
+    {
+        const int bound = imin(R.len - rp, Q.len - qp);
+        int n = start;
+        while (n < bound) {
+            u64 B = mism_fwd(qp + n, rp + n, imin(64, bound - n));
+            if (B) { n += ctz64(B); break; }
+            n += 64;
+        }
+        n = imin(n, bound);
+        return n > start ? n : start;
+    }
+
+    // Generic round: every lane evaluates its step completely (portable code of lzani_core.h).
+    __device__ __forceinline__ bool find_event_generic(int i, int n, bool trk, int r_end, int lit,
+                                                       int& ev_lane, int& bpos, int& blen) const
+    {
+        int bp = 0, bl = 0;
+        if (lane < n)
+            eval_step(P, R, Q, I, i + lane, trk && (lit + lane <= P.mqd), r_end, lit + lane, bp, bl);
+        u64 hit = __ballot(lane < n && bl >= P.msl);
+        if (!hit) return false;
+        ev_lane = ctz64(hit);
+        bpos = __builtin_amdgcn_readlane(bp, ev_lane);     // ev_lane is wave-uniform (from the ballot)
+        blen = __builtin_amdgcn_readlane(bl, ev_lane);
+        return true;
+    }
+
+    // Fast round (k-mer words available, seed window <= 128): the lanes only DETECT candidates --
+    // a bucket entry whose tag equals the step's mal-mer, a window position whose msl-mer equals the
+    // step's -- and the wave then verifies the candidates of the first candidate lane together
+    // (wave_equal_len), exactly as eval_step would for that step; if that step turns out not to hit
+    // (quirk Q1, or mal < msl) the next candidate lane is taken.
+    __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit,
+                                               int& ev_lane, int& bpos, int& blen) const
+    {
+        const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
+        const int W = nt > 0 ? imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end) : 0;
+        const int tb = I.kb - I.dirbits;
+        if (!FAST || W > 128 || (!BK && I.tagmask != (u32)lowmask(tb))) // the stored tag must identify the k-mer
+            return find_event_generic(i, n, trk, r_end, lit, ev_lane, bpos, blen);
+
+        // every independent load of the round first, unconditionally (the k-mer arrays are padded by two
+        // 64-entry blocks, so the addresses are always in bounds) and masked afterwards: no branches
+        u32 hq = qkL[(u32)(i + lane)], rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
+        hq = lane < n ? hq : KM_INVALID;
+        if (W > 0) {                                                 // wave-uniform
+            const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
+            qk = qkS[(u32)(i + lane)];
+            rk0 = rkS[(u32)(r_end + w0)];
+            rk1 = rkS[(u32)(r_end + w1)];
+            qk = lane < nt ? qk : KM_INVALID;
+            rk0 = lane < W ? rk0 : KM_INVALID;
+            rk1 = lane + 64 < W ? rk1 : KM_INVALID;
+        }
+        // anchor candidates of this lane's step: bucket entries carrying the step's (exact) tag.
+        //   BK: the bucket's tag word (4 B) says whether one of its first four entries carries the tag, or
+        //   that the bucket overflows (~0.03 % of buckets); the 16-byte bucket itself is read by the verify
+        //   step of a candidate only;
+        //   bucket table without tag words: one 16-byte load brings the bucket's first four entries, which stay
+        //   in registers for the verify step, an overflowing bucket sends the lane through the directory;
+        //   no bucket table (large genomes): directory + entries.
+        u32 aj = 0, ac = 0;
+        uint4 bkv = {BK_EMPTY, BK_EMPTY, BK_EMPTY, BK_EMPTY};
+        bool viadir = !BK && I.bk == nullptr;
+        if constexpr (BK) {
+            const bool valid = hq != KM_INVALID;
+            const u32 w = I.tw[valid ? hq >> tb : 0u];
+            const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);       // a zero byte = a slot with this tag
+            ac = (u32)(valid & ((((x - 0x01010101u) & ~x & 0x80808080u) != 0) | (w == TW_OVERFLOW)));
+        } else if (hq != KM_INVALID) {
+            const u32 b = hq >> tb, tag = hq & I.tagmask;
+            if (I.bk) {
+                bkv = reinterpret_cast<const uint4*>(I.bk)[b];
+                viadir = bkv.w == BK_OVERFLOW;
+                if (!viadir)                              // BK_EMPTY never carries a real tag (tag + position bits <= 30)
+                    ac = (u32)((bkv.x >> I.posbits) == tag) + (u32)((bkv.y >> I.posbits) == tag) +
+                         (u32)((bkv.z >> I.posbits) == tag) + (u32)((bkv.w >> I.posbits) == tag);
+            }
+            if (viadir) {
+                u32 s = I.dirz[b], e = I.dirz[b + 1];
+                if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
+                for (u32 j = s; j < e; ++j) {
+                    const bool m = (I.ent[j] >> I.posbits) == tag;
+                    aj = (m && ac == 0) ? j : aj;
+                    ac += m;
+                }
+            }
+        }
+        stamp(2);
+        u64 c0 = 0, c1 = 0;
+        if (W > 0) seed_join(lit, rk0, rk1, qk, c0, c1);
+        u64 todo = __ballot(ac != 0 || (c0 | c1) != 0);
+        stamp(7);
+        const u32 pm = (u32)lowmask(I.posbits);
+        while (todo) {
+            const int l = ctz64(todo);
+            todo &= todo - 1;
+            const int qp = i + l;
+            int ap = 0, al = 0;
+            const u32 cnt = __builtin_amdgcn_readlane(ac, l);
+            if (BK && cnt) {                                         // candidate step: now its bucket is read, by the wave
+                const u32 hql = (u32)__builtin_amdgcn_readlane((int)hq, l), tag = hql & I.tagmask;
+                const uint4 bq = reinterpret_cast<const uint4*>(I.bk)[hql >> tb];
+                const u32 en[4] = {(u32)__builtin_amdgcn_readfirstlane((int)bq.x), (u32)__builtin_amdgcn_readfirstlane((int)bq.y),
+                                   (u32)__builtin_amdgcn_readfirstlane((int)bq.z), (u32)__builtin_amdgcn_readfirstlane((int)bq.w)};
+                if (en[3] == BK_OVERFLOW) {                          // the whole bucket, ascending position
+                    u32 s = I.dirz[hql >> tb], e = I.dirz[(hql >> tb) + 1];
+                    if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
+                    for (u32 j = s; j < e; ++j) {
+                        const u32 x = (u32)__builtin_amdgcn_readfirstlane((int)I.ent[j]);
+                        if ((x >> I.posbits) != tag) continue;
+                        const int p = (int)(x & pm);
+                        const int m = wave_equal_len(p, qp, 0);
+                        if (m >= P.mal && m > al) { al = m; ap = p; }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if ((en[k] >> I.posbits) != tag) continue;
+                        const int p = (int)(en[k] & pm);
+                        const int m = wave_equal_len(p, qp, 0);
+                        if (m >= P.mal && m > al) { al = m; ap = p; }
+                    }
+                }
+            } else if (cnt) {
+                if (__builtin_amdgcn_readlane((int)viadir, l)) {
+                    const u32 j0 = __builtin_amdgcn_readlane(aj, l);
+                    for (u32 k = 0; k < cnt; ++k) {                  // same k-mer, ascending position
+                        const int p = (int)(I.ent[j0 + k] & pm);
+                        const int m = wave_equal_len(p, qp, 0);
+                        if (m >= P.mal && m > al) { al = m; ap = p; }
+                    }
+                } else {                                             // the step's bucket is still in registers
+                    const u32 tag = (u32)__builtin_amdgcn_readlane((int)hq, l) & I.tagmask;
+                    const u32 en[4] = {(u32)__builtin_amdgcn_readlane((int)bkv.x, l), (u32)__builtin_amdgcn_readlane((int)bkv.y, l),
+                                       (u32)__builtin_amdgcn_readlane((int)bkv.z, l), (u32)__builtin_amdgcn_readlane((int)bkv.w, l)};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if ((en[k] >> I.posbits) != tag) continue;
+                        const int p = (int)(en[k] & pm);
+                        const int m = wave_equal_len(p, qp, 0);
+                        if (m >= P.mal && m > al) { al = m; ap = p; }
+                    }
+                }
+            }
+            int bp = ap, bl = al;
+            if (l < nt) {
+                int sp = 0, sl = 0;
+                const int ref_pred = r_end + lit + l;
+                u64 d0 = bcast64(c0, l), d1 = bcast64(c1, l);
+                while (d0 | d1) {
+                    int idx;
+                    if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
+                    else { idx = 64 + ctz64(d1); d1 &= d1 - 1; }
+                    seed_consider(r_end + idx, wave_equal_len(r_end + idx, qp, P.msl), ref_pred, sp, sl);
+                }
+                arbitrate(P, R.len, lit + l, ap, al, sp, sl);
+                bp = sp; bl = sl;
+            }
+            if (bl >= P.msl) { ev_lane = l; bpos = bp; blen = bl; return true; }
+        }
+        return false;
+    }
+    __device__ __forceinline__ ExtMasks ext_scan(u64 prevB, u64 B, int n) const
+    {
+        bool b, q;
+        ext_lane(prevB, B, lane, n, P.aw, P.am, P.ar, b, q);
+        ExtMasks m;
+        m.brk = __ballot(b);
+        m.qual = __ballot(q);
+        return m;
+    }
+    __device__ __forceinline__ int best_split(u64 Lm, u64 Rm, int to_scan) const
+    {
+        // lane s scores split s; to_scan can be 64, so split 64 is scored by every lane too
+        int key = -1;
+        if (lane <= to_scan) key = (popc64(Lm & lowmask(lane)) + popc64(Rm >> lane)) * 128 + lane;
+        if (to_scan == 64) key = imax(key, popc64(Lm) * 128 + 64);
+        for (int d = 32; d >= 1; d >>= 1) key = imax(key, __shfl_xor(key, d));
+        return key & 127;
+    }
+};
+
+struct PairArgs {
+    GenomeTab G;
+    Params P;
+    IndexGeom geo;
+    const u32* dirz;
+    const u32* ent;
+    u64 dir_stride, ent_stride;
+    const u32* bk;           // bucket tables (4 entries per bucket) or nullptr
+    u64 bk_stride;
+    const u32* tw;           // tag words (one per bucket) or nullptr
+    u64 tw_stride;
+    const u32* ref_ids;      // device, batch-relative rows
+    const u64* row_off;      // device, batch-relative rows (+1), absolute pair offsets
+    const u32* query_ids;    // device, absolute pair offsets, or nullptr for dense rows
+    int* out;                // 3 ints per pair, absolute pair offsets
+    // Work queues, one per XCD: queue x owns the batch rows qorder[qb[x] .. qb[x+1]); qcum is the
+    // running pair count over qorder.  All waves of an XCD pull from that XCD's queue, so the 32 CUs
+    // sharing one 4 MiB L2 work on the same reference (its 0.8 MB index stays L2-resident); an XCD
+    // whose queue runs dry steals from the next one.  Placement is a speed matter only.
+    const u32* qorder;
+    const u64* qcum;
+    u32 qb[NQUEUES + 1];
+    unsigned long long* cursor;   // NQUEUES tickets counters
+    lzani_region* reg_out;        // alignment instantiation only
+    unsigned long long* reg_count;
+    unsigned long long reg_cap;
+};
+
+__device__ __forceinline__ u32 xcc_id()
+{
+    u32 x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7u;
+}
+
+// Instantiations: FAST = per-genome k-mer words exist (mal, msl <= 15); NFREE = no genome of the
+// context holds an N (the N mask is never consulted); DEFP = the LZ parameters are the reference's
+// defaults (params.h:34-48), folded into the code as constants.
+// ALN = also emit the regions of every pair (--out-alignment).
+template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false>
+__global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
+{
+    const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
+    const int lane = threadIdx.x & 63;
+    __shared__ u32 s_seed[4][SEED_LDS_WORDS];
+    u32* const lds = s_seed[threadIdx.x >> 6];
+    for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[SEED_SLOTS + 256 + k] = 0;
+    u32 qx = xcc_id() % NQUEUES, dry = 0;
+    for (;;) {
+        // One ticket per wave.  NB: this is the only lane-dependent branch of the persistent loop.
+        // A second `if (lane == 0)` at the loop tail (the result store) let the compiler thread the
+        // two branches across the back-edge and split lane 0 from lanes 1..63, which then spun on a
+        // dead lane's ticket; the store below is therefore done by every lane.
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(&a.cursor[qx], 1ULL);
+        const u32 tlo = __builtin_amdgcn_readfirstlane((u32)t);
+        const u32 thi = __builtin_amdgcn_readfirstlane((u32)(t >> 32));
+        const u32 rb = a.qb[qx], re = a.qb[qx + 1];
+        const u64 tk = a.qcum[rb] + (((u64)thi << 32) | tlo);
+        if (tk >= a.qcum[re]) {                   // this queue is dry: move on, leave after NQUEUES dry queues
+            if (++dry >= NQUEUES) break;
+            qx = (qx + 1) % NQUEUES;
+            continue;
+        }
+        u32 lo = rb, hi = re;                     // last row of the queue with qcum[row] <= tk
+        while (hi - lo > 1) {
+            u32 mid = (lo + hi) >> 1;
+            if (a.qcum[mid] <= tk) lo = mid; else hi = mid;
+        }
+        const u32 slot = a.qorder[lo];
+        const u32 r = a.ref_ids[slot];
+        const u32 j = (u32)(tk - a.qcum[lo]);
+        const u64 e = a.row_off[slot] + j;
+        const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
+
+        const int Lr = a.G.L[r], Lq = a.G.L[q];
+        const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
+        const int T = ref_text_len(Lr, Pk.mrd), D = Lq + Pk.mrd;
+        IndexView iv;
+        iv.dirz = a.dirz + slot * a.dir_stride;
+        iv.ent = a.ent + slot * a.ent_stride;
+        iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
+        iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
+        iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
+        const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
+        DevWave<FAST, BK> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
+                        qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
+                        lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128, lds + SEED_SLOTS + 256,
+                        FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
+                        FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
+        PairMachine<DevWave<FAST, BK>, ALN> m(w, Pk, T, D);
+        int res[3];
+#ifdef LZANI_STAMPS
+        for (int k = 0; k < 8; ++k) w.acc[k] = 0;
+        w.cur = 0;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.t0) :: "memory");
+#endif
+        m.run(res);
+#ifdef LZANI_STAMPS
+        w.stamp(0);
+        if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamp_acc[k], w.acc[k]);
+#endif
+        int* o = a.out + 3 * e;          // every lane stores the same wave-uniform values
+        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pairs_tpp: thread-per-pair variant.  Every lane owns one directed pair and runs the same pair
+// machine with the lane-serial policy (LaneWave, lzani_core.h): 64 independent pairs per wavefront,
+// no cross-lane traffic, the close seeds come from a second (msl) index of the reference.  Lanes pull
+// their pairs from the per-XCD queues one ticket each, so a finished lane never waits for its wave.
+// ------------------------------------------------------------------------------------------
+struct TppArgs {
+    PairArgs pa;
+    const u32* sdirz;        // seed index slabs, like dirz/ent
+    const u32* sent;
+    u64 sdir_stride, sent_stride;
+    IndexGeom sgeo;
+};
+
+template <bool NFREE, bool DEFP>
+__global__ void __launch_bounds__(256) k_pairs_tpp(TppArgs ta)
+{
+    const PairArgs& a = ta.pa;
+    const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
+    u32 qx = xcc_id() % NQUEUES, dry = 0;
+    for (;;) {
+        const unsigned long long t = atomicAdd(&a.cursor[qx], 1ULL);     // one ticket per lane
+        const u32 rb = a.qb[qx], re = a.qb[qx + 1];
+        const u64 tk = a.qcum[rb] + t;
+        if (tk >= a.qcum[re]) {
+            if (++dry >= NQUEUES) break;
+            qx = (qx + 1) % NQUEUES;
+            continue;
+        }
+        u32 lo = rb, hi = re;
+        while (hi - lo > 1) {
+            u32 mid = (lo + hi) >> 1;
+            if (a.qcum[mid] <= tk) lo = mid; else hi = mid;
+        }
+        const u32 slot = a.qorder[lo];
+        const u32 r = a.ref_ids[slot];
+        const u32 j = (u32)(tk - a.qcum[lo]);
+        const u64 e = a.row_off[slot] + j;
+        const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
+        const int Lr = a.G.L[r], Lq = a.G.L[q];
+        const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
+        const int T = ref_text_len(Lr, Pk.mrd), D = Lq + Pk.mrd;
+        IndexView iv, sv;
+        iv.dirz = a.dirz + slot * a.dir_stride;
+        iv.ent = a.ent + slot * a.ent_stride;
+        iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
+        iv.bk = nullptr; sv.bk = nullptr;
+        iv.tw = nullptr; sv.tw = nullptr;
+        sv.dirz = ta.sdirz + slot * ta.sdir_stride;
+        sv.ent = ta.sent + slot * ta.sent_stride;
+        sv.kb = ta.sgeo.kb; sv.dirbits = ta.sgeo.dirbits; sv.posbits = ta.sgeo.posbits; sv.tagmask = ta.sgeo.tagmask;
+        const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
+        LaneWave w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
+                   qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, sv,
+                   a.G.kmL + 64 * qo, a.G.kmS + 64 * qo};
+        PairMachine<LaneWave> m(w, Pk, T, D);
+        int res[3];
+        m.run(res);
+        int* o = a.out + 3 * e;
+        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+    }
+}
+
+}  // namespace lzani

@@ -41,8 +41,8 @@ class Timing(C.Structure):
 
 def build_library(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
-    deps = [SRC, os.path.join(HERE, "csrc", "lzani_core.h"), os.path.join(HERE, "csrc", "lzani_layout.h"),
-            os.path.join(ROOT, "include", "lzani.h")]
+    deps = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("lzani_core.h", "lzani_layout.h", "lzani_kernels_index.h",
+                                                             "lzani_kernels_pairs.h")] + [os.path.join(ROOT, "include", "lzani.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -5,16 +5,17 @@ cd /root/repo/lz-ani_amd
 python3 - <<'PY'
 import re
 s=open('csrc/lzani_hip.hip').read()
-s=s.replace('    __device__ __forceinline__ void stamp(int) const {}','    __device__ __forceinline__ void stamp(int) const {}')
-s=re.sub(r'(?<![\w.])stamp\((\d)\);', lambda m: 'asm volatile("; LZMARK %s");' % m.group(1), s)
 s=s.replace('"../../include/lzani.h"','"/root/repo/include/lzani.h"')
 open('/tmp/mark.hip','w').write(s)
+k=open('csrc/lzani_kernels_pairs.h').read()
+k=re.sub(r'(?<![\w.])stamp\((\d)\);', lambda m: 'asm volatile("; LZMARK %s");' % m.group(1), k)
+open('/tmp/lzani_kernels_pairs.h','w').write(k)
 c=open('csrc/lzani_core.h').read()
 c=re.sub(r'\bw\.stamp\((\d)\);', lambda m: 'LZMARK(%s);' % m.group(1), c)
 c=c.replace('namespace lzani {\n\ntypedef uint64_t u64;','#if defined(__HIP_DEVICE_COMPILE__)\n#define LZMARK(k) asm volatile("; LZMARK " #k)\n#else\n#define LZMARK(k)\n#endif\nnamespace lzani {\n\ntypedef uint64_t u64;',1)
 open('/tmp/lzani_core.h','w').write(c)
 PY
-cp csrc/lzani_layout.h /tmp/
+cp csrc/lzani_layout.h csrc/lzani_kernels_index.h /tmp/
 cd /tmp && rm -f mark-hip-* && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-value -save-temps -o /tmp/mark.so /tmp/mark.hip 2>/dev/null
 S=$(ls /tmp/mark-hip-amdgcn*gfx950*.s | head -1)
 awk "/^_ZN5lzani7${K}.*:/,/\.end_amdhsa_kernel/" $S > /tmp/kmark.s
