@@ -57,7 +57,7 @@ struct lzani_ctx {
 
     u32* d_dirz = nullptr;
     u32* d_ent = nullptr;
-    u32* d_bk = nullptr;          // bucket tables (viral-size directories only)
+    u32* d_bk = nullptr;          // bucket tables
     u64 bk_stride = 0;
     u32* d_tw = nullptr;          // tag words of the bucket tables (tag bits <= 7)
     u64 tw_stride = 0;
@@ -131,12 +131,14 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
         c->use_tpp = e && !strcmp(e, "tpp") && c->d_kmL &&
                      c->sgeo.tagmask == (u32)lowmask(c->sgeo.kb - c->sgeo.dirbits);
     }
-    {   // bucket table: only where it stays L2-sized (<= 2^18 buckets) and the sentinels cannot be real entries
+    {   // bucket table (+ tag words): wherever the sentinels cannot be real entries; 20 B per bucket more per slot
         int tagbits = 0;
         while (tagbits < 32 && ((c->geo.tagmask >> tagbits) & 1u)) ++tagbits;
         const bool exact = c->geo.tagmask == (u32)lowmask(c->geo.kb - c->geo.dirbits);
         const char* e = getenv("LZANI_NO_BUCKETS");
-        c->bk_stride = (c->d_kmL && exact && c->geo.dirbits <= 18 && tagbits + c->geo.posbits <= 30 && !(e && *e == '1'))
+        const char* mx = getenv("LZANI_BK_MAX_DIRBITS");                      // experiments
+        const int max_dirbits = mx ? atoi(mx) : 26;
+        c->bk_stride = (c->d_kmL && exact && c->geo.dirbits <= max_dirbits && tagbits + c->geo.posbits <= 30 && !(e && *e == '1'))
                            ? ((u64)4 << c->geo.dirbits) : 0;
         const char* t = getenv("LZANI_NO_TAGWORDS");
         c->tw_stride = (c->bk_stride && tagbits <= 7 && !(t && *t == '1')) ? ((u64)1 << c->geo.dirbits) : 0;
