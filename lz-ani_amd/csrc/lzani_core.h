@@ -78,7 +78,8 @@ LZ_HD int run_end(const TextView& t, int p)
 
 struct IndexView {        // anchor index of one reference (all mal-mers of R)
     const u32* dirz;      // dirz[b] .. dirz[b+1] = entry range of bucket b
-    const u32* ent;       // (tag << posbits) | pos, ascending inside a bucket
+    const u32* ent;       // (tag << posbits) | pos; ascending inside a bucket of up to IDX_SORT_MAX entries (larger
+                          // buckets - long low-complexity runs - stay in fill order)
     int kb;               // 2*mal key bits
     int dirbits;          // bucket = top dirbits of mix(key)
     int posbits;          // low bits of an entry hold the position
@@ -90,6 +91,7 @@ struct IndexView {        // anchor index of one reference (all mal-mers of R)
                           // four (no bucket looks like it: the tags of a bucket ascend with the slot)
 };
 enum : u32 { BK_EMPTY = 0xFFFFFFFFu, BK_OVERFLOW = 0xFFFFFFFEu, TW_OVERFLOW = 0x808080FFu };
+enum { IDX_SORT_MAX = 32 };
 
 // ---- bit helpers --------------------------------------------------------------------
 LZ_HD u64 lowmask(int n) { return n >= 64 ? ~0ULL : (n <= 0 ? 0ULL : ((1ULL << n) - 1ULL)); }
@@ -263,7 +265,7 @@ LZ_HD void anchor_lookup(const Params& P, const TextView& R, const TextView& Q, 
         if ((en >> I.posbits) != tag) continue;
         int p = (int)(en & pm);
         int m = equal_len(R, p, Q, qp, 0);
-        if (m >= P.mal && m > al) { al = m; ap = p; }
+        if (m >= P.mal && (m > al || (m == al && p < ap))) { al = m; ap = p; }   // no reliance on the bucket's order
     }
 }
 

@@ -59,6 +59,8 @@ struct lzani_ctx {
     u32* d_ent = nullptr;
     u32* d_bk = nullptr;          // bucket tables
     u64 bk_stride = 0;
+    u32* d_status = nullptr;      // per slot: the LDS index build left this slot to the global-atomics kernels
+    bool build_attr_set = false;
     u32* d_tw = nullptr;          // tag words of the bucket tables (tag bits <= 7)
     u64 tw_stride = 0;
     u32* d_sdirz = nullptr;       // seed (msl) index slabs, thread-per-pair kernel only
@@ -118,8 +120,8 @@ void free_genomes(lzani_ctx* c)
 }
 void free_slabs(lzani_ctx* c)
 {
-    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_sdirz); hipFree(c->d_sent); hipFree(c->d_bk); hipFree(c->d_tw);
-    c->d_dirz = c->d_ent = c->d_sdirz = c->d_sent = c->d_bk = c->d_tw = nullptr; c->slots = 0;
+    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_sdirz); hipFree(c->d_sent); hipFree(c->d_bk); hipFree(c->d_tw); hipFree(c->d_status);
+    c->d_dirz = c->d_ent = c->d_sdirz = c->d_sent = c->d_bk = c->d_tw = c->d_status = nullptr; c->slots = 0;
 }
 
 int ensure_slabs(lzani_ctx* c, u32 want_rows)
@@ -155,6 +157,7 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     HIPCHK(c, hipMalloc(&c->d_ent, (size_t)slots * c->ent_stride * 4));
     if (c->bk_stride) HIPCHK(c, hipMalloc(&c->d_bk, (size_t)slots * c->bk_stride * 4));
     if (c->tw_stride) HIPCHK(c, hipMalloc(&c->d_tw, (size_t)slots * c->tw_stride * 4));
+    HIPCHK(c, hipMalloc(&c->d_status, (size_t)slots * 4));
     if (c->use_tpp) {
         HIPCHK(c, hipMalloc(&c->d_sdirz, (size_t)slots * c->sdir_stride * 4));
         HIPCHK(c, hipMalloc(&c->d_sent, (size_t)slots * c->ent_stride * 4));
@@ -173,7 +176,7 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
     ia.ref_ids = d_ref_ids;
     ia.dirz = c->d_dirz; ia.ent = c->d_ent;
     ia.dir_stride = c->dir_stride; ia.ent_stride = c->ent_stride;
-    ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo; ia.seed = 0;
+    ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo; ia.seed = 0; ia.todo = nullptr;
     const u32 nb = 1u << c->geo.dirbits;
     if (c->d_kmL && !c->kmers_ready) {            // per-genome k-mer words, inside the timed index stage
         for (u32 g0 = 0; g0 < c->n; g0 += 32768) {
@@ -186,28 +189,47 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
         c->kmers_ready = true;
         c->tm.index_launches += 1;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_dirz, 0, (size_t)rows * c->dir_stride * 4, c->stream));
-    dim3 gp((c->Tmax + 255) / 256, rows);
+    const char* nolds = getenv("LZANI_NO_LDS_INDEX");
+    const bool lds_build = c->d_kmL && c->geo.dirbits <= 17 && !(nolds && *nolds == '1');
+    // blocks per slot of the global-atomics kernels: the whole range when they build every slot, a handful when
+    // they only pick up what k_idx_build left (usually nothing)
+    const u32 gx_pos = lds_build ? 16u : (u32)((c->Tmax + 255) / 256), gx_bkt = lds_build ? 16u : (nb + 255) / 256;
+    dim3 gp(gx_pos, rows);
+    if (lds_build) {
+        // one block per reference, everything through LDS; a slot that does not fit (status != 0) falls through
+        // to the global-atomics kernels below, which skip every other slot
+        const size_t lds = (size_t)(IDX_RANGE / 2 + IDX_STAGE) * 4;
+        if (!c->build_attr_set) {
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_idx_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            c->build_attr_set = true;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_status, 0, (size_t)rows * 4, c->stream));
+        hipLaunchKernelGGL(k_idx_build, dim3(rows), dim3(1024), lds, c->stream, ia, c->d_bk, c->d_tw, c->bk_stride, c->tw_stride, c->d_status);
+        ia.todo = c->d_status;
+        hipLaunchKernelGGL(k_idx_zero, dim3(gx_bkt, rows), dim3(256), 0, c->stream, c->d_dirz, c->dir_stride, nb, ia.todo);
+    } else HIPCHK(c, hipMemsetAsync(c->d_dirz, 0, (size_t)rows * c->dir_stride * 4, c->stream));
     hipLaunchKernelGGL(k_idx_count, gp, dim3(256), 0, c->stream, ia, c->Tmax);
-    hipLaunchKernelGGL(k_idx_scan, dim3(rows), dim3(1024), 0, c->stream, c->d_dirz, c->dir_stride, nb);
+    hipLaunchKernelGGL(k_idx_scan, dim3(rows), dim3(1024), 0, c->stream, c->d_dirz, c->dir_stride, nb, ia.todo);
     hipLaunchKernelGGL(k_idx_fill, gp, dim3(256), 0, c->stream, ia, c->Tmax);
-    hipLaunchKernelGGL(k_idx_sort, dim3((nb + 255) / 256, rows), dim3(256), 0, c->stream,
-                       c->d_dirz, c->d_ent, c->dir_stride, c->ent_stride, nb);
+    hipLaunchKernelGGL(k_idx_sort, dim3(gx_bkt, rows), dim3(256), 0, c->stream,
+                       c->d_dirz, c->d_ent, c->dir_stride, c->ent_stride, nb, ia.todo, 0);
     if (c->d_bk)
-        hipLaunchKernelGGL(k_idx_buckets, dim3((nb + 255) / 256, rows), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_idx_buckets, dim3(gx_bkt, rows), dim3(256), 0, c->stream,
                            c->d_dirz, c->d_ent, c->d_bk, c->d_tw, c->dir_stride, c->ent_stride, c->bk_stride, c->tw_stride,
-                           nb, c->geo.posbits);
+                           nb, c->geo.posbits, ia.todo);
     if (c->use_tpp) {                             // second index over the msl-mers
         IdxArgs sa = ia;
+        sa.todo = nullptr;
         sa.dirz = c->d_sdirz; sa.ent = c->d_sent; sa.dir_stride = c->sdir_stride;
         sa.mal = c->P.msl; sa.geo = c->sgeo; sa.seed = 1;
         const u32 snb = 1u << c->sgeo.dirbits;
         HIPCHK(c, hipMemsetAsync(c->d_sdirz, 0, (size_t)rows * c->sdir_stride * 4, c->stream));
-        hipLaunchKernelGGL(k_idx_count, gp, dim3(256), 0, c->stream, sa, c->Tmax);
-        hipLaunchKernelGGL(k_idx_scan, dim3(rows), dim3(1024), 0, c->stream, c->d_sdirz, c->sdir_stride, snb);
-        hipLaunchKernelGGL(k_idx_fill, gp, dim3(256), 0, c->stream, sa, c->Tmax);
+        const dim3 gs((c->Tmax + 255) / 256, rows);
+        hipLaunchKernelGGL(k_idx_count, gs, dim3(256), 0, c->stream, sa, c->Tmax);
+        hipLaunchKernelGGL(k_idx_scan, dim3(rows), dim3(1024), 0, c->stream, c->d_sdirz, c->sdir_stride, snb, (const u32*)nullptr);
+        hipLaunchKernelGGL(k_idx_fill, gs, dim3(256), 0, c->stream, sa, c->Tmax);
         hipLaunchKernelGGL(k_idx_sort, dim3((snb + 255) / 256, rows), dim3(256), 0, c->stream,
-                           c->d_sdirz, c->d_sent, c->sdir_stride, c->ent_stride, snb);
+                           c->d_sdirz, c->d_sent, c->sdir_stride, c->ent_stride, snb, (const u32*)nullptr, 1);
         c->tm.index_launches += 4;
     }
     HIPCHK(c, hipGetLastError());

@@ -88,6 +88,7 @@ struct IdxArgs {
     int mal, mrd;            // mal = the k of this index (min_anchor_len, or min_seed_len for the seed index)
     IndexGeom geo;
     int seed;                // 1: index of the msl-mers (key words from kmS, mixed here)
+    const u32* todo;         // per slot: nonzero = this slot is (re)built by the global-atomics kernels; nullptr = all
 };
 
 __device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, u32& bucket, u32& entry)
@@ -114,20 +115,32 @@ __device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, 
     return true;
 }
 
+// (count / fill / zero / sort / buckets walk their range with a grid-stride loop, so that the host can launch
+// them with a handful of blocks per slot when they only serve the few slots k_idx_build could not take)
 __global__ void k_idx_count(IdxArgs a, int Tmax)
 {
     u32 slot = blockIdx.y;
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= Tmax) return;
-    u32 b, e;
-    if (idx_slot_key(a, slot, p, b, e)) atomicAdd(&a.dirz[slot * a.dir_stride + 1 + b], 1u);
+    if (a.todo && !a.todo[slot]) return;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Tmax; p += gridDim.x * blockDim.x) {
+        u32 b, e;
+        if (idx_slot_key(a, slot, p, b, e)) atomicAdd(&a.dirz[slot * a.dir_stride + 1 + b], 1u);
+    }
+}
+
+// Zero the directories of the slots the global-atomics kernels have to (re)build.
+__global__ void k_idx_zero(u32* dirz, u64 dir_stride, u32 nb, const u32* todo)
+{
+    u32 slot = blockIdx.y;
+    if (!todo[slot]) return;
+    for (u32 b = blockIdx.x * blockDim.x + threadIdx.x; b <= nb; b += gridDim.x * blockDim.x) dirz[slot * dir_stride + b] = 0;
 }
 
 // In-place exclusive scan of the 2^dirbits bucket counts of one slot (one 1024-thread block).
-__global__ void __launch_bounds__(1024) k_idx_scan(u32* dirz, u64 dir_stride, u32 nb)
+__global__ void __launch_bounds__(1024) k_idx_scan(u32* dirz, u64 dir_stride, u32 nb, const u32* todo)
 {
     __shared__ u32 wsum[16];
     __shared__ u32 carry_s;
+    if (todo && !todo[blockIdx.x]) return;
     u32* cnt = dirz + (u64)blockIdx.x * dir_stride + 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
@@ -155,30 +168,173 @@ __global__ void __launch_bounds__(1024) k_idx_scan(u32* dirz, u64 dir_stride, u3
 __global__ void k_idx_fill(IdxArgs a, int Tmax)
 {
     u32 slot = blockIdx.y;
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= Tmax) return;
-    u32 b, e;
-    if (idx_slot_key(a, slot, p, b, e)) {
-        u32 at = atomicAdd(&a.dirz[slot * a.dir_stride + 1 + b], 1u);
-        a.ent[slot * a.ent_stride + at] = e;
+    if (a.todo && !a.todo[slot]) return;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Tmax; p += gridDim.x * blockDim.x) {
+        u32 b, e;
+        if (idx_slot_key(a, slot, p, b, e)) {
+            u32 at = atomicAdd(&a.dirz[slot * a.dir_stride + 1 + b], 1u);
+            a.ent[slot * a.ent_stride + at] = e;
+        }
     }
+}
+
+// k_idx_build: the whole anchor index of ONE reference by ONE 1024-thread block, through LDS (k-mer words
+// required, directories up to 2^17 buckets).  The global-atomics kernels above cost as much as ~45 pairs of the
+// same reference - too much for kmer-db-filtered rows of a few dozen pairs - and four fifths of that is the
+// scatter: 2 x T uncoalesced 4-byte accesses.  Here the buckets are taken in ranges of 16,384; per range
+//   count    16-bit LDS counters of the range's buckets over a sweep of the reference's k-mer words
+//   scan     exclusive prefix -> directory (coalesced); the counters become the buckets' END offsets
+//   place    second sweep: entry -> LDS staging at --end[bucket] (afterwards the counters are the STARTS)
+//   sort     inside every bucket of 2 .. IDX_SORT_MAX entries (ascending tag, position), one thread per bucket
+//   write    staging -> ent (contiguous: the ranges follow each other in ent), bucket table, tag words
+// so that every global access is coalesced and all random traffic stays in LDS.  A reference that does not
+// fit (a range with more than IDX_STAGE entries or a bucket of 65,535: long low-complexity runs) sets
+// status[slot] and is rebuilt by the global-atomics kernels, which skip every other slot.
+enum { IDX_RANGE = 16384, IDX_STAGE = 24576 };       // 32 KB of counters + 96 KB of staging
+
+__global__ void __launch_bounds__(1024) k_idx_build(IdxArgs a, u32* __restrict__ bk, u32* __restrict__ tw,
+                                                    u64 bk_stride, u64 tw_stride, u32* __restrict__ status)
+{
+    extern __shared__ u32 lds[];
+    u32* cnt = lds;                                  // IDX_RANGE / 2 words: two 16-bit counters each
+    u32* stage = lds + IDX_RANGE / 2;                // IDX_STAGE entries
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry_s, ovf_s;
+    const u32 slot = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const u32 g = a.ref_ids[slot];
+    const int T = ref_text_len(a.G.L[g], a.mrd);
+    const u32* km = a.G.kmL + 64 * a.G.nmoff[g];
+    const u32 nb = 1u << a.geo.dirbits;
+    const u32 rb = nb < (u32)IDX_RANGE ? nb : (u32)IDX_RANGE, rw = rb >> 1;       // buckets / counter words per range
+    const int tb = a.geo.kb - a.geo.dirbits, posbits = a.geo.posbits;
+    const u32 tagm = (u32)lowmask(tb) & a.geo.tagmask;
+    u32* dirz = a.dirz + slot * a.dir_stride;
+    u32* ent = a.ent + slot * a.ent_stride;
+    u32* bks = bk ? bk + slot * bk_stride : nullptr;
+    u32* tws = tw ? tw + slot * tw_stride : nullptr;
+    enum { U = 8 };                                  // k-mer words in flight per thread
+    if (tid == 0) ovf_s = 0;
+    u32 base = 0;                                    // entries of the ranges before this one
+    for (u32 r0 = 0; r0 < nb; r0 += rb) {
+        for (u32 k = tid; k < rw; k += 1024) cnt[k] = 0;
+        if (tid == 0) carry_s = 0;
+        __syncthreads();
+        // ---- count
+        for (int p0 = (int)tid; p0 < T; p0 += U * 1024) {
+            u32 v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) { const int p = p0 + k * 1024; v[k] = p < T ? km[p] : KM_INVALID; }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const u32 b = (v[k] >> tb) - r0;                     // KM_INVALID lands far outside every range
+                if (v[k] == KM_INVALID || b >= rb) continue;
+                const u32 sh = (b & 1) * 16;
+                const u32 old = atomicAdd(&cnt[b >> 1], 1u << sh);
+                if (((old >> sh) & 0xFFFFu) == 0xFFFFu) ovf_s = 1;
+            }
+        }
+        __syncthreads();
+        // ---- scan: directory out, counters -> end offsets inside the staging area
+        for (u32 w0 = 0; w0 < rw; w0 += 1024) {
+            const u32 idx = w0 + tid;
+            const u32 w = idx < rw ? cnt[idx] : 0;
+            const u32 c0 = w & 0xFFFFu, c1 = w >> 16;
+            const u32 v = c0 + c1;
+            u32 x = v;                               // inclusive scan inside the wave
+            for (int d = 1; d < 64; d <<= 1) {
+                u32 y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
+            if (lane == 63) wsum[wv] = x;
+            __syncthreads();
+            u32 woff = 0;
+            for (int k = 0; k < wv; ++k) woff += wsum[k];
+            const u32 carry = carry_s;
+            if (idx < rw) {
+                const u32 s0 = carry + woff + x - v;
+                dirz[r0 + 2 * idx] = base + s0;
+                dirz[r0 + 2 * idx + 1] = base + s0 + c0;
+                cnt[idx] = ((s0 + c0) & 0xFFFFu) | ((s0 + c0 + c1) << 16);         // ends (<= IDX_STAGE < 65536)
+            }
+            __syncthreads();
+            if (tid == 1023) carry_s = carry + woff + x;
+            __syncthreads();
+        }
+        const u32 total = carry_s;
+        if (total > (u32)IDX_STAGE && tid == 0) ovf_s = 1;
+        __syncthreads();
+        if (ovf_s) { if (tid == 0) status[slot] = 1; return; }
+        // ---- place
+        for (int p0 = (int)tid; p0 < T; p0 += U * 1024) {
+            u32 v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) { const int p = p0 + k * 1024; v[k] = p < T ? km[p] : KM_INVALID; }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const u32 b = (v[k] >> tb) - r0;
+                if (v[k] == KM_INVALID || b >= rb) continue;
+                const u32 sh = (b & 1) * 16;
+                const u32 at = ((atomicSub(&cnt[b >> 1], 1u << sh) >> sh) - 1u) & 0xFFFFu;
+                stage[at] = ((v[k] & tagm) << posbits) | (u32)(p0 + k * 1024);
+            }
+        }
+        __syncthreads();
+        // ---- sort inside the buckets; bucket table and tag words.  cnt now holds the starts; the end of a
+        //      bucket is the start of the next one (the range's total for the last).
+        for (u32 b = tid; b < rb; b += 1024) {
+            const u32 s = (cnt[b >> 1] >> ((b & 1) * 16)) & 0xFFFFu;
+            const u32 e = b + 1 < rb ? (cnt[(b + 1) >> 1] >> (((b + 1) & 1) * 16)) & 0xFFFFu : total;
+            for (u32 i = s + 1; i < e && e - s <= (u32)IDX_SORT_MAX; ++i) {
+                const u32 x = stage[i];
+                u32 j = i;
+                while (j > s && stage[j - 1] > x) { stage[j] = stage[j - 1]; --j; }
+                stage[j] = x;
+            }
+            if (bks) {
+                uint4 o;
+                o.x = s < e ? stage[s] : BK_EMPTY;
+                o.y = s + 1 < e ? stage[s + 1] : BK_EMPTY;
+                o.z = s + 2 < e ? stage[s + 2] : BK_EMPTY;
+                o.w = s + 3 < e ? stage[s + 3] : BK_EMPTY;
+                u32 w = 0;
+                if (s < e) w |= 0x80u | (o.x >> posbits);
+                if (s + 1 < e) w |= (0x80u | (o.y >> posbits)) << 8;
+                if (s + 2 < e) w |= (0x80u | (o.z >> posbits)) << 16;
+                if (s + 3 < e) w |= (0x80u | (o.w >> posbits)) << 24;
+                if (e - s > 4) { o.w = BK_OVERFLOW; w = TW_OVERFLOW; }
+                reinterpret_cast<uint4*>(bks)[r0 + b] = o;
+                if (tws) tws[r0 + b] = w;
+            }
+        }
+        __syncthreads();
+        for (u32 k = tid; k < total; k += 1024) ent[base + k] = stage[k];
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) dirz[nb] = base;
 }
 
 // Ascending order inside every bucket (candidate order = ascending reference position per
 // k-mer, the order of the reference's probe chain).  Buckets hold ~1 entry.
-__global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, u32 nb)
+// Buckets of more than IDX_SORT_MAX entries (long low-complexity runs: one k-mer hundreds of times) are left in
+// fill order unless `all` is set: an insertion sort by one thread is quadratic, and every reader of the anchor
+// index picks its candidate by (longest, then smallest position) without relying on the order.
+__global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, u32 nb, const u32* todo, int all)
 {
     u32 slot = blockIdx.y;
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+    if (todo && !todo[slot]) return;
     const u32* d = dirz + slot * dir_stride;
-    u32 s = d[b], e = d[b + 1];
     u32* v = ent + slot * ent_stride;
-    for (u32 i = s + 1; i < e; ++i) {
-        u32 x = v[i];
-        u32 j = i;
-        while (j > s && v[j - 1] > x) { v[j] = v[j - 1]; --j; }
-        v[j] = x;
+    for (u32 b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+        u32 s = d[b], e = d[b + 1];
+        if (e - s > (u32)IDX_SORT_MAX && !all) continue;
+        for (u32 i = s + 1; i < e; ++i) {
+            u32 x = v[i];
+            u32 j = i;
+            while (j > s && v[j - 1] > x) { v[j] = v[j - 1]; --j; }
+            v[j] = x;
+        }
     }
 }
 
@@ -189,29 +345,27 @@ __global__ void k_idx_sort(u32* dirz, u32* ent, u64 dir_stride, u64 ent_stride, 
 // waves of the XCD move from one reference to the next) and only a candidate step reads the 16-byte bucket.
 __global__ void k_idx_buckets(const u32* __restrict__ dirz, const u32* __restrict__ ent, u32* __restrict__ bk,
                               u32* __restrict__ tw, u64 dir_stride, u64 ent_stride, u64 bk_stride, u64 tw_stride,
-                              u32 nb, int posbits)
+                              u32 nb, int posbits, const u32* todo)
 {
     u32 slot = blockIdx.y;
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+    if (todo && !todo[slot]) return;
     const u32* d = dirz + slot * dir_stride;
     const u32* v = ent + slot * ent_stride;
-    const u32 s = d[b], e = d[b + 1];
-    uint4 o;
-    o.x = s < e ? v[s] : BK_EMPTY;
-    o.y = s + 1 < e ? v[s + 1] : BK_EMPTY;
-    o.z = s + 2 < e ? v[s + 2] : BK_EMPTY;
-    o.w = s + 3 < e ? v[s + 3] : BK_EMPTY;
-    if (e - s > 4) o.w = BK_OVERFLOW;
-    reinterpret_cast<uint4*>(bk + slot * bk_stride)[b] = o;
-    if (tw) {
+    for (u32 b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+        const u32 s = d[b], e = d[b + 1];
+        uint4 o;
+        o.x = s < e ? v[s] : BK_EMPTY;
+        o.y = s + 1 < e ? v[s + 1] : BK_EMPTY;
+        o.z = s + 2 < e ? v[s + 2] : BK_EMPTY;
+        o.w = s + 3 < e ? v[s + 3] : BK_EMPTY;
         u32 w = 0;
         if (s < e) w |= 0x80u | (o.x >> posbits);
         if (s + 1 < e) w |= (0x80u | (o.y >> posbits)) << 8;
         if (s + 2 < e) w |= (0x80u | (o.z >> posbits)) << 16;
         if (s + 3 < e) w |= (0x80u | (o.w >> posbits)) << 24;
-        if (e - s > 4) w = TW_OVERFLOW;
-        tw[slot * tw_stride + b] = w;
+        if (e - s > 4) { o.w = BK_OVERFLOW; w = TW_OVERFLOW; }
+        reinterpret_cast<uint4*>(bk + slot * bk_stride)[b] = o;
+        if (tw) tw[slot * tw_stride + b] = w;
     }
 }
 

@@ -205,6 +205,23 @@ struct DevWave {
         return true;
     }
 
+    // best_anchor over a whole bucket, by the wave: the longest match >= mal among the entries carrying the
+    // tag, the smallest position among equals - the reference's "first wins" over ascending positions
+    // (parser.cpp:514-531), stated without relying on the order (buckets beyond IDX_SORT_MAX stay unsorted).
+    __device__ __forceinline__ void walk_bucket(u32 b, u32 tag, int qp, int& ap, int& al) const
+    {
+        const u32 pm = (u32)lowmask(I.posbits);
+        u32 s = I.dirz[b], e = I.dirz[b + 1];
+        if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
+        for (u32 j = s; j < e; ++j) {
+            const u32 x = (u32)__builtin_amdgcn_readfirstlane((int)I.ent[j]);
+            if ((x >> I.posbits) != tag) continue;
+            const int p = (int)(x & pm);
+            const int m = wave_equal_len(p, qp, 0);
+            if (m >= P.mal && (m > al || (m == al && p < ap))) { al = m; ap = p; }
+        }
+    }
+
     // Fast round (k-mer words available, seed window <= 128): the lanes only DETECT candidates --
     // a bucket entry whose tag equals the step's mal-mer, a window position whose msl-mer equals the
     // step's -- and the wave then verifies the candidates of the first candidate lane together
@@ -239,7 +256,7 @@ struct DevWave {
         //   bucket table without tag words: one 16-byte load brings the bucket's first four entries, which stay
         //   in registers for the verify step, an overflowing bucket sends the lane through the directory;
         //   no bucket table (large genomes): directory + entries.
-        u32 aj = 0, ac = 0;
+        u32 ac = 0;
         uint4 bkv = {BK_EMPTY, BK_EMPTY, BK_EMPTY, BK_EMPTY};
         bool viadir = !BK && I.bk == nullptr;
         if constexpr (BK) {
@@ -259,11 +276,7 @@ struct DevWave {
             if (viadir) {
                 u32 s = I.dirz[b], e = I.dirz[b + 1];
                 if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
-                for (u32 j = s; j < e; ++j) {
-                    const bool m = (I.ent[j] >> I.posbits) == tag;
-                    aj = (m && ac == 0) ? j : aj;
-                    ac += m;
-                }
+                for (u32 j = s; j < e; ++j) ac += (I.ent[j] >> I.posbits) == tag;
             }
         }
         stamp(2);
@@ -283,16 +296,8 @@ struct DevWave {
                 const uint4 bq = reinterpret_cast<const uint4*>(I.bk)[hql >> tb];
                 const u32 en[4] = {(u32)__builtin_amdgcn_readfirstlane((int)bq.x), (u32)__builtin_amdgcn_readfirstlane((int)bq.y),
                                    (u32)__builtin_amdgcn_readfirstlane((int)bq.z), (u32)__builtin_amdgcn_readfirstlane((int)bq.w)};
-                if (en[3] == BK_OVERFLOW) {                          // the whole bucket, ascending position
-                    u32 s = I.dirz[hql >> tb], e = I.dirz[(hql >> tb) + 1];
-                    if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(2); e = s; }
-                    for (u32 j = s; j < e; ++j) {
-                        const u32 x = (u32)__builtin_amdgcn_readfirstlane((int)I.ent[j]);
-                        if ((x >> I.posbits) != tag) continue;
-                        const int p = (int)(x & pm);
-                        const int m = wave_equal_len(p, qp, 0);
-                        if (m >= P.mal && m > al) { al = m; ap = p; }
-                    }
+                if (en[3] == BK_OVERFLOW) {                          // the whole bucket (big buckets are not sorted)
+                    walk_bucket(hql >> tb, tag, qp, ap, al);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -303,15 +308,10 @@ struct DevWave {
                     }
                 }
             } else if (cnt) {
+                const u32 hql = (u32)__builtin_amdgcn_readlane((int)hq, l), tag = hql & I.tagmask;
                 if (__builtin_amdgcn_readlane((int)viadir, l)) {
-                    const u32 j0 = __builtin_amdgcn_readlane(aj, l);
-                    for (u32 k = 0; k < cnt; ++k) {                  // same k-mer, ascending position
-                        const int p = (int)(I.ent[j0 + k] & pm);
-                        const int m = wave_equal_len(p, qp, 0);
-                        if (m >= P.mal && m > al) { al = m; ap = p; }
-                    }
+                    walk_bucket(hql >> tb, tag, qp, ap, al);
                 } else {                                             // the step's bucket is still in registers
-                    const u32 tag = (u32)__builtin_amdgcn_readlane((int)hq, l) & I.tagmask;
                     const u32 en[4] = {(u32)__builtin_amdgcn_readlane((int)bkv.x, l), (u32)__builtin_amdgcn_readlane((int)bkv.y, l),
                                        (u32)__builtin_amdgcn_readlane((int)bkv.z, l), (u32)__builtin_amdgcn_readlane((int)bkv.w, l)};
 #pragma unroll

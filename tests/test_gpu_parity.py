@@ -15,6 +15,16 @@ import util as U
 pytestmark = pytest.mark.gpu
 
 
+
+def _bucketwise_sorted(dirz, ent):
+    """Entries with every bucket sorted: the device leaves buckets of more than IDX_SORT_MAX entries in fill order."""
+    out = ent.copy()
+    big = np.nonzero(np.diff(dirz.astype(np.int64)) > 32)[0]
+    for b in big:
+        out[dirz[b]:dirz[b + 1]] = np.sort(out[dirz[b]:dirz[b + 1]])
+    return out
+
+
 def gpu_all2all(seqs, params=None):
     eng = L.Engine(params)
     try:
@@ -74,7 +84,7 @@ def test_device_built_text_and_index_match_model():
                                    O._ptr(dirz), O._ptr(ent), C.byref(n_ent)) == 0
             assert np.array_equal(d["t2"], t2) and np.array_equal(d["nm"], nm)
             assert np.array_equal(d["dirz"], dirz)
-            assert n_ent.value == len(d["ent"]) and np.array_equal(d["ent"], ent[:n_ent.value])
+            assert n_ent.value == len(d["ent"]) and np.array_equal(_bucketwise_sorted(d["dirz"], d["ent"]), ent[:n_ent.value])
         eng.close()
 
 
@@ -303,6 +313,46 @@ def test_index_forms(monkeypatch, env):
             got = np.stack([mine[k] for k in cols], axis=1) if len(mine) else np.zeros((0, 6), np.int32)
             assert np.array_equal(got, want), (env, r, q)
             e += 1
+
+
+@pytest.mark.parametrize("env", [{}, {"LZANI_NO_LDS_INDEX": "1"}], ids=["lds-build", "global-atomics"])
+def test_index_build_paths(monkeypatch, env):
+    """k_idx_build (one block per reference through LDS) and its fallback: references the LDS build cannot take
+    (a poly-A genome: one bucket holds every k-mer; a long tandem repeat; a genome with a 30 kbp low-complexity
+    insert) are rebuilt by the global-atomics kernels inside the same run.  Directory and entries must equal the
+    host model's for every genome, and the pair results the oracle's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    st = SG.Stream(5)
+    rnd = lambda n: (st.u64(n) % np.uint64(4)).astype(np.uint8)
+    base = rnd(40000)
+    seqs = [base, SG.mutate(base, 0.05, st), rnd(36000),
+            np.concatenate([rnd(9000), np.tile(np.array([0, 1, 2, 3, 3, 1], np.uint8), 80), rnd(9000)]),
+            np.zeros(50000, np.uint8), np.tile(np.array([0, 1, 2, 3, 3, 1], np.uint8), 8000),
+            np.concatenate([rnd(8000), np.full(30000, 3, np.uint8), rnd(8000)])]
+    lib = U.model_lib()
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    maxlen = max(len(s) for s in seqs)
+    for gid, s in enumerate(seqs):
+        d = eng.debug_index(gid)
+        T = 2 * len(s) + 3 * eng.params["mrd"]
+        wn = (T + 63) // 64 + 2
+        t2 = np.zeros(2 * wn, np.uint64); nm = np.zeros(wn, np.uint64)
+        dirz = np.zeros(len(d["dirz"]), np.uint32); ent = np.zeros(T + 1, np.uint32)
+        n_ent = C.c_uint32(0)
+        s = np.ascontiguousarray(s)
+        assert lib.model_index(O._ptr(s), len(s), maxlen, O.params_array(None), O._ptr(t2), O._ptr(nm),
+                               O._ptr(dirz), O._ptr(ent), C.byref(n_ent)) == 0
+        assert np.array_equal(d["dirz"], dirz), gid
+        assert n_ent.value == len(d["ent"]) and np.array_equal(_bucketwise_sorted(d["dirz"], d["ent"]), ent[:n_ent.value]), gid
+        small = np.diff(d["dirz"].astype(np.int64)) <= 32                     # small buckets come sorted from the device
+        for b in np.nonzero(small & (np.diff(d["dirz"].astype(np.int64)) > 1))[0][:2000]:
+            seg = d["ent"][d["dirz"][b]:d["dirz"][b + 1]]
+            assert np.all(seg[:-1] <= seg[1:]), (gid, int(b))
+    eng.close()
+    # pairs: without the three degenerate genomes (a poly-A pair is quadratic for every implementation)
+    assert np.array_equal(gpu_all2all(seqs[:4]), O.oracle_all2all(seqs[:4], None, threads=16))
 
 
 def test_thread_per_pair_variant(monkeypatch):
