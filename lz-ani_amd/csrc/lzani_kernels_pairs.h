@@ -12,8 +12,7 @@ namespace lzani {
 // ------------------------------------------------------------------------------------------
 // k_pairs: the pair kernel.
 // ------------------------------------------------------------------------------------------
-enum { SEED_SLOT_BITS = 8, SEED_SLOTS = 1 << SEED_SLOT_BITS, SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5),
-       SEED_LDS_WORDS = SEED_SLOTS + 256 + SEED_BM_WORDS, NQUEUES = 8 };
+enum { SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5), SEED_LDS_WORDS = SEED_BM_WORDS, NQUEUES = 8 };
 
 // FAST: per-position k-mer words exist;  BK: the bucket table and its tag words exist
 template <bool FAST, bool BK = false>
@@ -22,10 +21,7 @@ struct DevWave {
     TextView R, Q;
     IndexView I;
     int lane;
-    u32* heads;      // per-wave LDS: SEED_SLOTS chain heads
-    u32* nexts;      // 128 chain links
-    u32* keys;       // 128 window msl-mers
-    u32* bitmap;     // SEED_BM_WORDS words, all zero between rounds
+    u32* bitmap;     // per-wave LDS: SEED_BM_WORDS words, all zero between rounds
     const u32* rkS;  // FAST: msl-mers of the reference text, one per position
     const u32* qkL;  // FAST: hashed mal-mers of the query text
     const u32* qkS;  // FAST: msl-mers of the query text
@@ -112,25 +108,21 @@ struct DevWave {
         A = __ballot((lane < na) & ma);
         B = __ballot((lane < nb) & mb);
     }
-    // Close-seed search of all tracking lanes of a round at once (replaces the ht_short bucket walk,
-    // parser.cpp:548-580).  rk0/rk1 = msl-mers of the window positions r_end+lane / r_end+64+lane,
-    // qk = msl-mer of this lane's step (KM_INVALID where there is none).
-    //  1. prefilter: the window k-mers set bits in a per-wave 16 Kbit LDS bitmap (exact for msl <= 7,
-    //     a Bloom filter above), each tracking lane tests its own k-mer; in four rounds out of five no
-    //     lane hits and the search ends here (the bits are cleared again, the bitmap is always zero
-    //     between rounds);
-    //  2. otherwise the window k-mers are chained into a small LDS hash table and every hit lane
-    //     walks the chain of its k-mer, collecting the matching positions below its own window limit
-    //     into a 128-bit mask; candidates are then taken in ascending position, the order of the
-    //     reference's bucket.
+    // Close-seed search of the tracking steps of a round (replaces the ht_short bucket walk, parser.cpp:548-580).
+    // rk0/rk1 = msl-mers of the window positions r_end+lane / r_end+64+lane, qk = msl-mer of this lane's step
+    // (KM_INVALID where there is none).
+    //  1. seed_prefilter: the window k-mers set bits in a per-wave 16 Kbit LDS bitmap (exact for msl <= 7, a
+    //     Bloom filter above), each tracking lane tests its own k-mer; the bits are cleared again (the bitmap
+    //     is always zero between rounds).  In four rounds out of five of an unrelated pair no lane hits.
+    //  2. seed_candidates: when the verify loop reaches a hit lane, that lane's k-mer is broadcast and compared
+    //     with the window k-mers, which are still in registers: two ballots give the lane's candidate positions
+    //     (ascending = the order of the reference's bucket) - no join structure at all.
     __device__ __forceinline__ u32 bm_hash(u32 k) const
     {
         return P.msl <= 7 ? k : (k * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
     }
-    __device__ __forceinline__ void seed_join(int lit, u32 rk0, u32 rk1, u32 qk, u64& c0, u64& c1) const
+    __device__ __forceinline__ bool seed_prefilter(u32 rk0, u32 rk1, u32 qk) const
     {
-        c0 = 0; c1 = 0;
-        const u32 EMPTY = 0xFFFFFFFFu;
         const u32 b0 = bm_hash(rk0), b1 = bm_hash(rk1), bq = bm_hash(qk);
         if (rk0 != KM_INVALID) atomicOr(&bitmap[b0 >> 5], 1u << (b0 & 31));
         if (rk1 != KM_INVALID) atomicOr(&bitmap[b1 >> 5], 1u << (b1 & 31));
@@ -138,37 +130,17 @@ struct DevWave {
         __builtin_amdgcn_wave_barrier();
         bool hit = false;
         if (qk != KM_INVALID) hit = (bitmap[bq >> 5] >> (bq & 31)) & 1u;
-        const u64 any = __ballot(hit);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (rk0 != KM_INVALID) bitmap[b0 >> 5] = 0;
         if (rk1 != KM_INVALID) bitmap[b1 >> 5] = 0;
-        if (!any) return;
-
-        for (int k = 0; k < SEED_SLOTS / 64; ++k) heads[lane + 64 * k] = EMPTY;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (rk0 != KM_INVALID) {
-            keys[lane] = rk0;
-            nexts[lane] = atomicExch(&heads[(rk0 * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)], (u32)lane);
-        }
-        if (rk1 != KM_INVALID) {
-            keys[lane + 64] = rk1;
-            nexts[lane + 64] = atomicExch(&heads[(rk1 * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)], (u32)lane + 64);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (hit) {
-            const u32 lim = (u32)(lit + lane + P.mrd);          // this step's window is [0, lim)
-            int guard = 0;
-            for (u32 h = heads[(qk * 0x9E3779B1u) >> (32 - SEED_SLOT_BITS)]; h != EMPTY; h = nexts[h]) {
-                if (++guard > 128) { LZ_GUARD_TRIP(4); break; }
-                const u64 bit = (u64)(keys[h] == qk && h < lim) << (h & 63);
-                c0 |= h < 64 ? bit : 0;
-                c1 |= h < 64 ? 0 : bit;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        return hit;
+    }
+    // window positions idx < lim (the step's own window) whose msl-mer equals the step's (qkl, wave-uniform)
+    __device__ __forceinline__ void seed_candidates(u32 qkl, int lim, u32 rk0, u32 rk1, u64& d0, u64& d1) const
+    {
+        d0 = __ballot(rk0 == qkl) & lowmask(lim);
+        d1 = __ballot(rk1 == qkl) & lowmask(lim - 64);
     }
 
     __device__ __forceinline__ u64 bcast64(u64 v, int l) const      // readlane returns a signed int: widen as u32
@@ -280,9 +252,9 @@ struct DevWave {
             }
         }
         stamp(2);
-        u64 c0 = 0, c1 = 0;
-        if (W > 0) seed_join(lit, rk0, rk1, qk, c0, c1);
-        u64 todo = __ballot(ac != 0 || (c0 | c1) != 0);
+        bool shit = false;
+        if (W > 0) shit = seed_prefilter(rk0, rk1, qk);
+        u64 todo = __ballot(ac != 0 || shit);
         stamp(7);
         const u32 pm = (u32)lowmask(I.posbits);
         while (todo) {
@@ -327,7 +299,9 @@ struct DevWave {
             if (l < nt) {
                 int sp = 0, sl = 0;
                 const int ref_pred = r_end + lit + l;
-                u64 d0 = bcast64(c0, l), d1 = bcast64(c1, l);
+                u64 d0 = 0, d1 = 0;
+                const u32 qkl = (u32)__builtin_amdgcn_readlane((int)qk, l);
+                if (qkl != KM_INVALID) seed_candidates(qkl, lit + l + P.mrd, rk0, rk1, d0, d1);
                 while (d0 | d1) {
                     int idx;
                     if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
@@ -407,7 +381,7 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
     const int lane = threadIdx.x & 63;
     __shared__ u32 s_seed[4][SEED_LDS_WORDS];
     u32* const lds = s_seed[threadIdx.x >> 6];
-    for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[SEED_SLOTS + 256 + k] = 0;
+    for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[k] = 0;
     u32 qx = xcc_id() % NQUEUES, dry = 0;
     for (;;) {
         // One ticket per wave.  NB: this is the only lane-dependent branch of the persistent loop.
@@ -448,7 +422,7 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
         DevWave<FAST, BK> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                         qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
-                        lds, lds + SEED_SLOTS, lds + SEED_SLOTS + 128, lds + SEED_SLOTS + 256,
+                        lds,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
                         FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
         PairMachine<DevWave<FAST, BK>, ALN> m(w, Pk, T, D);
