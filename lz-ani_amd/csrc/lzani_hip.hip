@@ -190,7 +190,8 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
         c->tm.index_launches += 1;
     }
     const char* nolds = getenv("LZANI_NO_LDS_INDEX");
-    const bool lds_build = c->d_kmL && c->geo.dirbits <= 17 && !(nolds && *nolds == '1');
+    const char* ldsmax = getenv("LZANI_LDS_INDEX_MAX_DIRBITS");
+    const bool lds_build = c->d_kmL && c->geo.dirbits <= (ldsmax ? atoi(ldsmax) : 19) && !(nolds && *nolds == '1');
     // blocks per slot of the global-atomics kernels: the whole range when they build every slot, a handful when
     // they only pick up what k_idx_build left (usually nothing)
     const u32 gx_pos = lds_build ? 16u : (u32)((c->Tmax + 255) / 256), gx_bkt = lds_build ? 16u : (nb + 255) / 256;

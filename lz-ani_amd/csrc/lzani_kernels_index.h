@@ -179,7 +179,8 @@ __global__ void k_idx_fill(IdxArgs a, int Tmax)
 }
 
 // k_idx_build: the whole anchor index of ONE reference by ONE 1024-thread block, through LDS (k-mer words
-// required, directories up to 2^17 buckets).  The global-atomics kernels above cost as much as ~45 pairs of the
+// required; used for directories up to 2^19 buckets - beyond that the 2 x 2^dirbits / 16,384 sweeps over the
+// k-mer words cost more than the global atomics).  The global-atomics kernels above cost as much as ~45 pairs of the
 // same reference - too much for kmer-db-filtered rows of a few dozen pairs - and four fifths of that is the
 // scatter: 2 x T uncoalesced 4-byte accesses.  Here the buckets are taken in ranges of 16,384; per range
 //   count    16-bit LDS counters of the range's buckets over a sweep of the reference's k-mer words

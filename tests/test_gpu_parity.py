@@ -355,6 +355,35 @@ def test_index_build_paths(monkeypatch, env):
     assert np.array_equal(gpu_all2all(seqs[:4]), O.oracle_all2all(seqs[:4], None, threads=16))
 
 
+def test_index_build_mid_size_directories():
+    """k_idx_build beyond viral size: 2^18 and 2^19 buckets (16 and 32 bucket ranges per reference)."""
+    st = SG.Stream(8)
+    a = (st.u64(100_000) % np.uint64(4)).astype(np.uint8)
+    b = (st.u64(230_000) % np.uint64(4)).astype(np.uint8)
+    sets = ([a, SG.mutate(a, 0.04, st), SG.mutate(a, 0.12, st)], [b, SG.mutate(b, 0.06, st), a])
+    lib = U.model_lib()
+    for seqs in sets:
+        eng = L.Engine()
+        eng.set_genomes(seqs)
+        maxlen = max(len(s) for s in seqs)
+        for gid, s in enumerate(seqs):
+            d = eng.debug_index(gid)
+            assert d["geom"][1] in (18, 19)
+            T = 2 * len(s) + 3 * eng.params["mrd"]
+            wn = (T + 63) // 64 + 2
+            t2 = np.zeros(2 * wn, np.uint64); nm = np.zeros(wn, np.uint64)
+            dirz = np.zeros(len(d["dirz"]), np.uint32); ent = np.zeros(T + 1, np.uint32)
+            n_ent = C.c_uint32(0)
+            s = np.ascontiguousarray(s)
+            assert lib.model_index(O._ptr(s), len(s), maxlen, O.params_array(None), O._ptr(t2), O._ptr(nm),
+                                   O._ptr(dirz), O._ptr(ent), C.byref(n_ent)) == 0
+            assert np.array_equal(d["dirz"], dirz), gid
+            assert n_ent.value == len(d["ent"]) and np.array_equal(_bucketwise_sorted(d["dirz"], d["ent"]), ent[:n_ent.value]), gid
+        got = eng.all2all()
+        eng.close()
+        assert np.array_equal(got, O.oracle_all2all(seqs, None, threads=16))
+
+
 def test_thread_per_pair_variant(monkeypatch):
     """The opt-in thread-per-pair kernel (LZANI_KERNEL=tpp; slower, kept for experiments) is bit-exact too."""
     monkeypatch.setenv("LZANI_KERNEL", "tpp")
