@@ -424,3 +424,14 @@ def test_differential_fuzz_gpu_vs_oracle():
         got = gpu_all2all(seqs, prm)
         want = O.oracle_all2all(seqs, prm, threads=4)
         assert np.array_equal(got, want), (it, prm, np.argwhere((got != want).any(axis=2))[:3].tolist())
+
+
+def test_differential_fuzz_medium_genomes():
+    """The same at 8-70 kbp: tag words, bucket table and the LDS index build are in use, parameters random
+    (mal <= 12), genomes with N runs and inversions."""
+    st = SG.Stream(777)
+    for it in range(60):
+        prm, seqs = U.fuzz_case_medium(st)
+        got = gpu_all2all(seqs, prm)
+        want = O.oracle_all2all(seqs, prm, threads=16)
+        assert np.array_equal(got, want), (it, prm, np.argwhere((got != want).any(axis=2))[:3].tolist())

@@ -185,6 +185,35 @@ def model_pair_regions(ref, qry, params=None):
     return tuple(int(x) for x in res), g[order]
 
 
+DEFAULTS = dict(mal=11, msl=7, mrd=40, mqd=40, reg=35, aw=15, am=7, ar=3)
+
+
+def fuzz_case_medium(st):
+    """Like fuzz_case, at genome sizes where the tag words, the bucket table and the LDS index build are in
+    use (8-70 kbp, mal <= 12): an ancestor, two mutated copies (one with an inversion or N runs), one stranger."""
+    msl = st.randint(4, 9)
+    mal = st.randint(max(msl, 9), 12)
+    mrd = st.randint(8, 64)
+    prm = dict(mal=mal, msl=msl, mrd=mrd, mqd=st.randint(4, min(mrd, 64)), reg=st.randint(10, 80), aw=st.randint(4, 40),
+               am=st.randint(1, 12), ar=st.randint(1, 6))
+    if st.one() < 0.3:
+        prm = dict(DEFAULTS)
+    L = st.randint(8000, 70000)
+    base = (st.u64(L) % np.uint64(4)).astype(np.uint8)
+    seqs = [base, SG.mutate(base, 0.01 + 0.12 * st.one(), st)]
+    g = SG.mutate(base, 0.02 + 0.2 * st.one(), st).copy()
+    if st.one() < 0.5:
+        for _ in range(st.randint(1, 3)):
+            a = st.randint(0, len(g) - 200)
+            g[a:a + st.randint(1, 120)] = 5
+    else:
+        a = st.randint(0, len(g) - 3000)
+        g[a:a + 2500] = (3 - g[a:a + 2500][::-1])
+    seqs.append(np.ascontiguousarray(g))
+    seqs.append((st.u64(st.randint(8000, 70000)) % np.uint64(4)).astype(np.uint8))
+    return prm, seqs
+
+
 def fuzz_case(st):
     """One random differential case: LZ parameters inside the engine's envelope with mqd <= mrd (beyond
     that the reference reads past the end of its reference text, parser.cpp:288/713, and its answer

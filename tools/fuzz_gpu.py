@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Long differential fuzz of the HIP path against the oracle.  Usage: tools/fuzz_gpu.py [seed] [seconds]"""
+"""Long differential fuzz of the HIP path against the oracle.  Usage: tools/fuzz_gpu.py [seed] [seconds] [medium]
+`medium`: 8-70 kbp genomes (tag words, bucket table, LDS index build in use) instead of the tiny ones."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("lz-ani_amd", "oracle", "tools", "tests"):
@@ -12,14 +13,15 @@ import util as U
 
 st = SG.Stream(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
+medium = len(sys.argv) > 3 and sys.argv[3] == "medium"
 t0, it, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     it += 1
-    prm, seqs = U.fuzz_case(st)
+    prm, seqs = U.fuzz_case_medium(st) if medium else U.fuzz_case(st)
     eng = L.Engine(prm)
     eng.set_genomes(seqs)
     got = eng.all2all()
-    want = O.oracle_all2all(seqs, prm, threads=4)
+    want = O.oracle_all2all(seqs, prm, threads=16 if medium else 4)
     if not np.array_equal(got, want):
         bad += 1
         print("MISMATCH", prm, [len(s) for s in seqs], np.argwhere((got != want).any(axis=2))[:3].tolist(), flush=True)
