@@ -55,25 +55,32 @@ struct TextView {         // one packed text: `len` symbols are addressable
     const u64* nm;        // 1 bit per symbol, 1 = N / padding
     int len;
     // Structure of a text whose genome holds no N: the only N symbols are the pads, so the valid
-    // symbols are [0, L) and, in a reference text, [rc0, rc0 + L); rc0 < 0 in a query view.
+    // symbols are [0, L) and, in a reference text, [rc0, rc0 + L); rc0 = NO_RC (beyond every position) in a
+    // query view.
     // With nfree set on both sides the N mask is never loaded (bounds do its job).
     int L, rc0;
     bool nfree;
 };
 
+enum { NO_RC = 0x40000000 };
 LZ_HD TextView ref_view(const u64* t2, const u64* nm, int L, int mrd, bool nfree)
 { return TextView{t2, nm, 2 * L + 3 * mrd, L, L + 2 * mrd, nfree}; }
 LZ_HD TextView qry_view(const u64* t2, const u64* nm, int L, int mrd, bool nfree)
-{ return TextView{t2, nm, L + mrd, L, -1, nfree}; }
+{ return TextView{t2, nm, L + mrd, L, NO_RC, nfree}; }
 
 // N-free texts: is p a real symbol / where does the run of real symbols containing p end
-LZ_HD bool pos_valid(const TextView& t, int p)      // branch-free: unsigned range tests, bitwise combination
-{ return ((u32)p < (u32)t.L) | ((t.rc0 >= 0) & ((u32)(p - t.rc0) < (u32)t.L)); }
+LZ_HD bool pos_valid(const TextView& t, int p)
+{
+    // p folded onto [0, L): p itself before rc0, p - rc0 from rc0 on (the smaller of the two as unsigned; a
+    // negative p or a pad position stays >= L).  One compare, no lane-mask logic (that would be scalar work).
+    const u32 a = (u32)p, b = (u32)(p - t.rc0);
+    return (a < b ? a : b) < (u32)t.L;
+}
 LZ_HD int run_end(const TextView& t, int p)
 {
     // with mrd = 0 no pad separates the forward part from the reverse complement: one run [0, 2L)
     if (p < t.L) return (t.rc0 == t.L) ? t.rc0 + t.L : t.L;
-    return (t.rc0 >= 0 && p >= t.rc0 && p < t.rc0 + t.L) ? t.rc0 + t.L : p;
+    return (p >= t.rc0 && p < t.rc0 + t.L) ? t.rc0 + t.L : p;
 }
 
 struct IndexView {        // anchor index of one reference (all mal-mers of R)
@@ -705,7 +712,7 @@ struct LaneWave {
     LZ_HD u64 valid_bits(const TextView& t, int p0) const          // bit j: p0 + j is a real symbol position
     {
         u64 v = bits_range(-p0, t.L - p0);
-        if (t.rc0 >= 0) v |= bits_range(t.rc0 - p0, t.rc0 + t.L - p0);
+        if (t.rc0 != NO_RC) v |= bits_range(t.rc0 - p0, t.rc0 + t.L - p0);
         return v;
     }
     LZ_HD u64 mism_fwd(int q0, int r0, int n) const
