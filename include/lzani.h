@@ -116,7 +116,9 @@ int lzani_get_timing(const lzani_ctx *ctx, lzani_timing *t);
 
 /* Test hook: copies out the device-built packed reference text and anchor index of one genome
  * (any pointer may be NULL).  Sizes: nm = ((T+63)/64+2) u64, t2 = twice that, with
- * T = 2*len+3*mrd; dirz = 2^dirbits+1 u32; ent <= T u32.  geom = {kb, dirbits, posbits, tagmask}. */
+ * T = 2*len+3*mrd; dirz = 2^dirbits+1 u32; ent <= T u32.  geom = {kb, dirbits, posbits, tagmask}.
+ * Entries ascend inside every bucket of up to 32 entries; larger buckets (long low-complexity runs) are in
+ * fill order, which no reader of the index depends on. */
 int lzani_debug_get_index(lzani_ctx *ctx, uint32_t id, uint64_t *t2, uint64_t *nm,
                           uint32_t *dirz, uint32_t *ent, uint32_t *n_ent, uint32_t *geom);
 
