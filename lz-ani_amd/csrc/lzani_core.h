@@ -515,7 +515,7 @@ struct PairMachine {
             mm_cum += popc64(B);
             prevB = B;
         }
-        if (last > 0) {            // position last-1 is a match, so every mismatch precedes a match
+        if (__builtin_expect(last > 0, 0)) {   // position last-1 is a match, so every mismatch precedes a match
             g.cl += last - last_mm;
             g.clit += g.nl + last_mm;
             g.nl = 0;
@@ -613,7 +613,7 @@ struct PairMachine {
             } else {
                 // distant match (parser.cpp:636-685)
                 int avail;
-                if (prev_rs >= 0 && prev_re - prev_rs < P.reg) {       // drop the short region
+                if (__builtin_expect(prev_rs >= 0 && prev_re - prev_rs < P.reg, 1)) {       // drop the short region
                     avail = pre_lit + (i - prev_rs);
                     g.discard();
                     if (ALN) c.clear();
@@ -629,9 +629,9 @@ struct PairMachine {
                 int b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;
                 g.finalize();                                           // a match_distant factor follows
                 region_close();
-                if (b > 0) {
+                if (__builtin_expect(b > 0, 0)) {
                     pre_lit = avail - b;
-                    if (b <= nb) {                                      // forward order = the b mask bits reversed
+                    if (__builtin_expect(b <= nb, 1)) {                 // forward order = the b mask bits reversed
                         const u64 M = brev64(~Bb & lowmask(b)) >> (64 - b);
                         g.seg(M, b);
                         if (ALN) runs(M, b, i - b, bpos - b, 0);

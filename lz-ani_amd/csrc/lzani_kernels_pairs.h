@@ -205,7 +205,7 @@ struct DevWave {
         const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
         const int W = nt > 0 ? imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end) : 0;
         const int tb = I.kb - I.dirbits;
-        if (!FAST || W > 128 || (!BK && I.tagmask != (u32)lowmask(tb))) // the stored tag must identify the k-mer
+        if (__builtin_expect(!FAST || W > 128 || (!BK && I.tagmask != (u32)lowmask(tb)), 0)) // the stored tag must identify the k-mer
             return find_event_generic(i, n, trk, r_end, lit, ev_lane, bpos, blen);
 
         // every independent load of the round first, unconditionally (the k-mer arrays are padded by two
@@ -268,7 +268,7 @@ struct DevWave {
                 const uint4 bq = reinterpret_cast<const uint4*>(I.bk)[hql >> tb];
                 const u32 en[4] = {(u32)__builtin_amdgcn_readfirstlane((int)bq.x), (u32)__builtin_amdgcn_readfirstlane((int)bq.y),
                                    (u32)__builtin_amdgcn_readfirstlane((int)bq.z), (u32)__builtin_amdgcn_readfirstlane((int)bq.w)};
-                if (en[3] == BK_OVERFLOW) {                          // the whole bucket (big buckets are not sorted)
+                if (__builtin_expect(en[3] == BK_OVERFLOW, 0)) {     // the whole bucket (big buckets are not sorted)
                     walk_bucket(hql >> tb, tag, qp, ap, al);
                 } else {
 #pragma unroll
@@ -311,7 +311,7 @@ struct DevWave {
                 arbitrate(P, R.len, lit + l, ap, al, sp, sl);
                 bp = sp; bl = sl;
             }
-            if (bl >= P.msl) { ev_lane = l; bpos = bp; blen = bl; return true; }
+            if (__builtin_expect(bl >= P.msl, 1)) { ev_lane = l; bpos = bp; blen = bl; return true; }
         }
         return false;
     }
