@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genomes", type=int, default=0, help="0 = 1000*sqrt(gpus)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=128, help="genomes in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="genomes in the CPU baseline sample (0 = skip)")
     ap.add_argument("--lmin", type=int, default=36000, help="ancestor length range of the synthetic set")
     ap.add_argument("--lmax", type=int, default=44000)
     ap.add_argument("--params", default="", help="LZ parameter overrides, e.g. mal=15,msl=9,reg=60 (BASELINE configs[3])")
