@@ -265,9 +265,12 @@ struct DevWave {
             const u32 cnt = __builtin_amdgcn_readlane(ac, l);
             if (BK && cnt) {                                         // candidate step: now its bucket is read, by the wave
                 const u32 hql = (u32)__builtin_amdgcn_readlane((int)hq, l), tag = hql & I.tagmask;
-                const uint4 bq = reinterpret_cast<const uint4*>(I.bk)[hql >> tb];
-                const u32 en[4] = {(u32)__builtin_amdgcn_readfirstlane((int)bq.x), (u32)__builtin_amdgcn_readfirstlane((int)bq.y),
-                                   (u32)__builtin_amdgcn_readfirstlane((int)bq.z), (u32)__builtin_amdgcn_readfirstlane((int)bq.w)};
+                // the bucket's address is wave-uniform: a scalar load (the table is read-only during the launch)
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 bq;
+                const u32* bptr = I.bk + 4 * (u64)(hql >> tb);
+                asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bq) : "s"(bptr) : "memory");
+                const u32 en[4] = {bq.x, bq.y, bq.z, bq.w};
                 if (__builtin_expect(en[3] == BK_OVERFLOW, 0)) {     // the whole bucket (big buckets are not sorted)
                     walk_bucket(hql >> tb, tag, qp, ap, al);
                 } else {
