@@ -268,8 +268,11 @@ struct DevWave {
                 // the bucket's address is wave-uniform: a scalar load (the table is read-only during the launch)
                 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
                 u32x4 bq;
-                const u32* bptr = I.bk + 4 * (u64)(hql >> tb);
-                asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bq) : "s"(bptr) : "memory");
+                const u64 baddr = (u64)(I.bk + 4 * (u64)(hql >> tb));
+                // (the address through readfirstlane: an "s" operand must be in SGPRs whatever the allocator did)
+                const u64 bsgpr = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(baddr >> 32)) << 32) |
+                                  (u32)__builtin_amdgcn_readfirstlane((int)(u32)baddr);
+                asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bq) : "s"(bsgpr) : "memory");
                 const u32 en[4] = {bq.x, bq.y, bq.z, bq.w};
                 if (__builtin_expect(en[3] == BK_OVERFLOW, 0)) {     // the whole bucket (big buckets are not sorted)
                     walk_bucket(hql >> tb, tag, qp, ap, al);
