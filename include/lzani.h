@@ -114,6 +114,68 @@ int lzani_run_rows_regions(lzani_ctx *ctx, uint32_t n_rows, const uint32_t *ref_
 
 int lzani_get_timing(const lzani_ctx *ctx, lzani_timing *t);
 
+/* What the context laid out in HBM for the current genome set (after lzani_set_genomes), and how the last
+ * lzani_run_rows* call was batched.  The reference has no counterpart (its tables are private members of
+ * CParser, parser.h:25-56); tests and the bench use it to assert which index form / batch path really ran. */
+typedef struct lzani_layout_info {
+    int32_t  key_bits, dir_bits, pos_bits;  /* anchor index geometry: 2*mal, log2(buckets), bits of a text position */
+    uint32_t tag_mask;                      /* tag bits stored in an entry                                            */
+    int32_t  kmer_words;                    /* 1: per-genome k-mer words exist (mal, msl <= 15)                      */
+    int32_t  bucket_table, tag_words;       /* 1: the index slabs carry a bucket table / tag words                   */
+    int32_t  n_free;                        /* 1: no genome holds an N (NFREE kernel instantiation)                  */
+    uint32_t slots;                         /* index slabs allocated = reference rows per batch                      */
+    uint32_t batches_last_run;              /* batches of the last run                                               */
+    uint64_t bytes_per_slot;                /* HBM bytes of one index slab                                           */
+    uint64_t bytes_genomes;                 /* HBM bytes of packed texts + N masks + k-mer words                     */
+} lzani_layout_info;
+int lzani_get_layout(const lzani_ctx *ctx, lzani_layout_info *info);
+
+/* ---- Sharding over GPUs ---------------------------------------------------------------
+ * The unit that shards is the reference's own work unit, one reference ROW (lz_matcher.cpp:196-255: a worker
+ * takes a reference, builds its index once and parses every query of the row).  Rows are independent; the
+ * genome set is replicated on every GPU; the only exchange is one gather of the per-pair results.
+ * The reference itself self-schedules rows over threads with an atomic counter (lz_matcher.cpp:200); over
+ * GPUs the rows are dealt up front by the partition below. */
+
+/* cost(row) = sum of the row's query lengths + LZANI_ROW_COST_REF_WEIGHT * reference length: a pair costs
+ * time proportional to its query length, the per-row index build that of a few pairs. */
+#define LZANI_ROW_COST_REF_WEIGHT 6
+int lzani_row_costs(uint32_t n_rows, const uint32_t *ref_ids, const uint64_t *row_off, const uint32_t *query_ids,
+                    uint32_t n, const uint32_t *len, uint64_t *cost);
+
+/* part_of_row[k] in [0, n_parts): row_cost == NULL deals the rows cyclically (dense all2all rows in the
+ * reordered, length-descending id order cost the same); otherwise greedy longest-processing-time
+ * (heaviest row first onto the least loaded shard) for the ragged rows a kmer-db filter leaves
+ * (filter.cpp:301-345, lz_matcher.cpp:234-250).  Pure host function: needs no GPU. */
+int lzani_partition_rows(uint32_t n_rows, const uint64_t *row_cost, uint32_t n_parts, uint32_t *part_of_row);
+
+/* One process per GPU (torchrun / MPI launchers): an RCCL communicator bound to the context's device and
+ * stream.  Rank 0 obtains an id, the caller distributes the LZANI_UNIQUE_ID_BYTES bytes by any means (file,
+ * torch.distributed, MPI_Bcast), every rank calls lzani_comm_init.  Buffers are device pointers.
+ *   allgather: every rank contributes n_results records (padded equal shards), every rank receives
+ *              n_ranks * n_results in rank order;
+ *   gatherv:   rank p contributes counts[p] records, the root receives them concatenated in rank order
+ *              (grouped ncclSend / ncclRecv; d_recv is ignored elsewhere). */
+#define LZANI_UNIQUE_ID_BYTES 128
+int lzani_comm_unique_id(uint8_t *id);
+int lzani_comm_init(lzani_ctx *ctx, uint32_t n_ranks, uint32_t rank, const uint8_t *id);
+int lzani_comm_allgather(lzani_ctx *ctx, const void *d_send, void *d_recv, uint64_t n_results);
+int lzani_comm_gatherv(lzani_ctx *ctx, const void *d_send, void *d_recv, const uint64_t *counts, uint32_t root);
+
+/* One process, several GPUs (what `lz-ani --gpus n` uses): a context per listed device, each driven by its
+ * own host thread; lzani_group_run_rows has the contract of lzani_run_rows -- it partitions the rows as above,
+ * runs every shard on its device, gathers the shards on the first device over RCCL (ncclCommInitAll + grouped
+ * ncclSend/ncclRecv), restores the caller's CSR order there and copies the results out once.
+ * Listing one device twice is allowed for rehearsals on a single GPU (shards then move by device copies). */
+typedef struct lzani_group lzani_group;
+int lzani_group_create(const lzani_params *p, uint32_t n_devices, const int *device_ids, lzani_group **out);
+void lzani_group_destroy(lzani_group *grp);
+const char *lzani_group_last_error(const lzani_group *grp);
+int lzani_group_set_genomes(lzani_group *grp, uint32_t n, const uint8_t *const *codes, const uint32_t *len);
+int lzani_group_run_rows(lzani_group *grp, uint32_t n_rows, const uint32_t *ref_ids, const uint64_t *row_off,
+                         const uint32_t *query_ids, lzani_result *out);
+int lzani_group_get_timing(const lzani_group *grp, uint32_t device_index, lzani_timing *t, double *gather_ms);
+
 /* Test hook: copies out the device-built packed reference text and anchor index of one genome
  * (any pointer may be NULL).  Sizes: nm = ((T+63)/64+2) u64, t2 = twice that, with
  * T = 2*len+3*mrd; dirz = 2^dirbits+1 u32; ent <= T u32.  geom = {kb, dirbits, posbits, tagmask}.

@@ -19,8 +19,8 @@
 //
 // The file is shared by the HIP kernels (wave = 64 lanes, lzani_kernels_pairs.h) and by the host-side
 // models used only by the tests (tests/model/): the state machine (PairMachine) is templated on a
-// `Wave` policy that supplies the cross-lane primitives -- DevWave on the device (ballots, LDS),
-// a lane-emulating policy and the lane-serial LaneWave on the host.
+// `Wave` policy that supplies the cross-lane primitives -- DevWave on the device (ballots, LDS);
+// the tests have two host policies of their own (tests/model/: lane-emulating, and lane-serial).
 #pragma once
 #include <stdint.h>
 
@@ -656,143 +656,6 @@ struct PairMachine {
         region_close();
         out[0] = g.tm; out[1] = g.tl; out[2] = g.tc;
     }
-};
-
-
-// ---- lane-serial policy ------------------------------------------------------------------------
-// The same machine driven by ONE lane per pair: every "wave" primitive is computed by the lane alone
-// with word-parallel bit tricks (2-bit XOR + even-bit compress for the mismatch masks, shift-and for
-// the match runs, a walk over the mismatch bits for the window break), and the scan advances one
-// step at a time.  Used by the thread-per-pair kernel (64 independent pairs per wavefront) and, on the
-// host, as a second model of the algorithm.
-LZ_HD u64 compress_even(u64 x)        // bits 0,2,4,.. of x -> bits 0..31
-{
-    x &= 0x5555555555555555ULL;
-    x = (x | (x >> 1)) & 0x3333333333333333ULL;
-    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
-    x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
-    return x;
-}
-LZ_HD u64 bits_below(int n) { return lowmask(n < 0 ? 0 : n); }       // bits j < n, n clamped to [0,64]
-LZ_HD u64 bits_range(int a, int b) { return bits_below(b) & ~bits_below(a); }
-// Anchor-style index lookup of the close seeds of one tracking step (replaces the ht_short bucket walk,
-// parser.cpp:548-580): positions p in [r_end, ref_pred + mrd) holding the step's msl-mer, ascending.
-LZ_HD void seed_lookup(const Params& P, const TextView& R, const TextView& Q, const IndexView& S,
-                       u64 qk, int qp, int r_end, int lit, int& sp, int& sl)
-{
-    sp = 0; sl = 0;
-    const u64 h = mix_key(qk, S.kb);
-    const int tb = S.kb - S.dirbits;
-    const u32 b = (u32)(h >> tb), tag = (u32)(h & lowmask(tb)) & S.tagmask;
-    u32 s = S.dirz[b], e = S.dirz[b + 1];
-    if (e - s > (u32)R.len || e < s) { LZ_GUARD_TRIP(5); return; }
-    const u32 pm = (u32)lowmask(S.posbits);
-    const int ref_pred = r_end + lit;
-    const int hi = imin(ref_pred + P.mrd, R.len - P.msl + 1);
-    for (u32 j = s; j < e; ++j) {
-        const u32 en = S.ent[j];
-        if ((en >> S.posbits) != tag) continue;
-        const int p = (int)(en & pm);
-        if (p < r_end || p >= hi) continue;
-        seed_consider(p, equal_len(R, p, Q, qp, P.msl), ref_pred, sp, sl);
-    }
-}
-
-struct LaneWave {
-    const Params& P;
-    TextView R, Q;
-    IndexView A, S;            // anchor (mal) and seed (msl) indexes of the reference; S tags must be exact
-    const u32* qkL;            // optional per-position k-mer words of the query (nullptr: extract from the text)
-    const u32* qkS;
-
-    LZ_HD void stamp(int) const {}
-
-    LZ_HD u64 valid_bits(const TextView& t, int p0) const          // bit j: p0 + j is a real symbol position
-    {
-        u64 v = bits_range(-p0, t.L - p0);
-        if (t.rc0 != NO_RC) v |= bits_range(t.rc0 - p0, t.rc0 + t.L - p0);
-        return v;
-    }
-    LZ_HD u64 mism_fwd(int q0, int r0, int n) const
-    {
-        if (n <= 0) return 0;
-        if (q0 < 0 || r0 < 0) {                                   // only near the text start: symbol by symbol
-            u64 m = 0;
-            for (int j = 0; j < n; ++j) if (!sym_match(R, r0 + j, Q, q0 + j)) m |= 1ULL << j;
-            return m;
-        }
-        u64 mm = 0;
-        for (int k = 0; k < 64 && k < n; k += 32) {
-            u64 x = win2(R.t2, r0 + k) ^ win2(Q.t2, q0 + k);
-            mm |= compress_even(x | (x >> 1)) << k;
-        }
-        u64 valid;
-        if (R.nfree && Q.nfree) valid = valid_bits(R, r0) & valid_bits(Q, q0);
-        else valid = ~(winN(R.nm, r0) | winN(Q.nm, q0)) & bits_below(R.len - r0) & bits_below(Q.len - q0);
-        return (mm | ~valid) & lowmask(n);
-    }
-    LZ_HD u64 mism_bwd(int q0, int r0, int n) const                // bit j: Q[q0-1-j] vs R[r0-1-j]
-    {
-        if (n <= 0) return 0;
-        u64 f = mism_fwd(q0 - n, r0 - n, n);                      // bit t: Q[q0-n+t]; reverse the n bits
-        return brev64(f) >> (64 - n);
-    }
-    LZ_HD void mism2(int qa, int ra, int da, int na, int qb, int rb, int db, int nb, u64& A, u64& B) const
-    {
-        A = da > 0 ? mism_fwd(qa, ra, na) : mism_bwd(qa + 1, ra + 1, na);
-        B = db > 0 ? mism_fwd(qb, rb, nb) : mism_bwd(qb + 1, rb + 1, nb);
-    }
-    LZ_HD ExtMasks ext_scan(u64 prevB, u64 B, int n) const
-    {
-        ExtMasks m{0, 0};
-        const int a = P.ar < 1 ? 1 : P.ar;
-        const u64 Z = ~B, Zp = ~prevB;
-        u64 acc = Z;
-        for (int k = 1; k < a; ++k) acc &= (Z << k) | (Zp >> (64 - k));
-        m.qual = acc & lowmask(n);
-        u64 mmbits = B & lowmask(n);                               // a break can only sit on a mismatch (am >= 0)
-        while (mmbits) {
-            const int j = ctz64(mmbits);
-            mmbits &= mmbits - 1;
-            const u64 W = (B << (63 - j)) | ((prevB >> 1) >> j);
-            if (popc64(W >> (64 - P.aw)) > P.am) { m.brk = 1ULL << j; break; }
-        }
-        return m;
-    }
-    LZ_HD int best_split(u64 Lm, u64 Rm, int to_scan) const
-    {
-        int best = -1, bs = 0;
-        for (int s = 0; s <= to_scan; ++s) {
-            int v = popc64(Lm & lowmask(s)) + (s >= 64 ? 0 : popc64(Rm >> s));
-            if (v >= best) { best = v; bs = s; }
-        }
-        return bs;
-    }
-    LZ_HD bool find_event(int i, int n, bool trk, int r_end, int lit, int& lane, int& bpos, int& blen) const
-    {
-        for (int l = 0; l < n; ++l) {
-            const int qp = i + l;
-            int ap = 0, al = 0;
-            if (qkL) { const u32 h = qkL[qp]; if (h != 0xFFFFFFFFu) anchor_lookup(P, R, Q, A, h, qp, ap, al); }
-            else best_anchor(P, R, Q, A, qp, ap, al);
-            int bp = ap, bl = al;
-            if (trk && lit + l <= P.mqd) {
-                int sp = 0, sl = 0;
-                u64 qk = 0;
-                bool ok;
-                if (qkS) { const u32 v = qkS[qp]; ok = v != 0xFFFFFFFFu; qk = v; }
-                else ok = kmer_at(Q, qp, P.msl, qk);
-                if (ok) seed_lookup(P, R, Q, S, qk, qp, r_end, lit + l, sp, sl);
-                arbitrate(P, R.len, lit + l, ap, al, sp, sl);
-                bp = sp; bl = sl;
-            }
-            if (bl >= P.msl) { lane = l; bpos = bp; blen = bl; return true; }
-        }
-        return false;
-    }
-    LZ_HD void emit_region(const RegionCoords&) const {}
 };
 
 }  // namespace lzani

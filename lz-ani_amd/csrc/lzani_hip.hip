@@ -2,7 +2,7 @@
 //
 // The kernels (all integer / bit work; no MFMA by design) live in two headers included below:
 //   lzani_kernels_index.h   k_pack, k_kmers, k_idx_*   genomes -> packed texts, k-mer words, anchor indexes
-//   lzani_kernels_pairs.h   DevWave, k_pairs, k_pairs_tpp   the pair kernels
+//   lzani_kernels_pairs.h   DevWave, k_pairs   the pair kernel
 // The algorithm itself (PairMachine and its building blocks, shared with the host model of the tests) is
 // lzani_core.h; sizes and the parameter envelope are lzani_layout.h.
 #include <hip/hip_runtime.h>
@@ -36,7 +36,8 @@ struct lzani_ctx {
     Params P;
     int dev = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> events;    // four per batch of a run (index begin/end, pairs begin/end)
+    int n_cus = 256;
     std::string err;
 
     u32 n = 0;
@@ -63,16 +64,16 @@ struct lzani_ctx {
     bool build_attr_set = false;
     u32* d_tw = nullptr;          // tag words of the bucket tables (tag bits <= 7)
     u64 tw_stride = 0;
-    u32* d_sdirz = nullptr;       // seed (msl) index slabs, thread-per-pair kernel only
-    u32* d_sent = nullptr;
-    u64 sdir_stride = 0;
-    IndexGeom sgeo{};
-    bool use_tpp = false;
     u32 slots = 0;
+    u32 batches_last_run = 0;
+    u32 max_slots = 65535;        // gridDim.y limit; LZANI_MAX_SLOTS lowers it (tests force the multi-batch path)
     u64 dir_stride = 0, ent_stride = 0;
     unsigned long long* d_cursor = nullptr;
 
     lzani_timing tm{};
+
+    void* comm = nullptr;         // ncclComm_t of lzani_comm_init (one process per GPU), lzani_multi.h
+    u32 n_ranks = 1, rank = 0;
 };
 
 namespace {
@@ -120,37 +121,37 @@ void free_genomes(lzani_ctx* c)
 }
 void free_slabs(lzani_ctx* c)
 {
-    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_sdirz); hipFree(c->d_sent); hipFree(c->d_bk); hipFree(c->d_tw); hipFree(c->d_status);
-    c->d_dirz = c->d_ent = c->d_sdirz = c->d_sent = c->d_bk = c->d_tw = c->d_status = nullptr; c->slots = 0;
+    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_bk); hipFree(c->d_tw); hipFree(c->d_status);
+    c->d_dirz = c->d_ent = c->d_bk = c->d_tw = c->d_status = nullptr; c->slots = 0;
+}
+
+// The form of the anchor index (bucket table, tag words) is a property of the genome set and the parameters:
+// decided once per lzani_set_genomes, so the strides of the slabs never change under an allocation.
+void choose_index_form(lzani_ctx* c)
+{
+    int tagbits = 0;
+    while (tagbits < 32 && ((c->geo.tagmask >> tagbits) & 1u)) ++tagbits;
+    const bool exact = c->geo.tagmask == (u32)lowmask(c->geo.kb - c->geo.dirbits);
+    const char* e = getenv("LZANI_NO_BUCKETS");                           // experiments / test_index_forms
+    const char* mx = getenv("LZANI_BK_MAX_DIRBITS");
+    const int max_dirbits = mx ? atoi(mx) : 26;
+    // bucket table (+ tag words): wherever the sentinels cannot be real entries; 20 B per bucket more per slot
+    c->bk_stride = (c->d_kmL && exact && c->geo.dirbits <= max_dirbits && tagbits + c->geo.posbits <= 30 && !(e && *e == '1'))
+                       ? ((u64)4 << c->geo.dirbits) : 0;
+    const char* t = getenv("LZANI_NO_TAGWORDS");
+    c->tw_stride = (c->bk_stride && tagbits <= 7 && !(t && *t == '1')) ? ((u64)1 << c->geo.dirbits) : 0;
+    const char* ms = getenv("LZANI_MAX_SLOTS");
+    c->max_slots = ms && atoi(ms) > 0 ? (u32)std::min(65535, atoi(ms)) : 65535u;
 }
 
 int ensure_slabs(lzani_ctx* c, u32 want_rows)
 {
-    {   // thread-per-pair kernel: diagnostic opt-in (LZANI_KERNEL=tpp); needs the k-mer words and exact seed tags
-        const char* e = getenv("LZANI_KERNEL");
-        c->sgeo = index_geometry(c->Tmax, c->P.msl);
-        c->sdir_stride = ((u64)1 << c->sgeo.dirbits) + 1;
-        c->use_tpp = e && !strcmp(e, "tpp") && c->d_kmL &&
-                     c->sgeo.tagmask == (u32)lowmask(c->sgeo.kb - c->sgeo.dirbits);
-    }
-    {   // bucket table (+ tag words): wherever the sentinels cannot be real entries; 20 B per bucket more per slot
-        int tagbits = 0;
-        while (tagbits < 32 && ((c->geo.tagmask >> tagbits) & 1u)) ++tagbits;
-        const bool exact = c->geo.tagmask == (u32)lowmask(c->geo.kb - c->geo.dirbits);
-        const char* e = getenv("LZANI_NO_BUCKETS");
-        const char* mx = getenv("LZANI_BK_MAX_DIRBITS");                      // experiments
-        const int max_dirbits = mx ? atoi(mx) : 26;
-        c->bk_stride = (c->d_kmL && exact && c->geo.dirbits <= max_dirbits && tagbits + c->geo.posbits <= 30 && !(e && *e == '1'))
-                           ? ((u64)4 << c->geo.dirbits) : 0;
-        const char* t = getenv("LZANI_NO_TAGWORDS");
-        c->tw_stride = (c->bk_stride && tagbits <= 7 && !(t && *t == '1')) ? ((u64)1 << c->geo.dirbits) : 0;
-    }
-    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + (c->use_tpp ? c->sdir_stride + c->ent_stride : 0));
+    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride);
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     size_t have = c->slots * per_slot;
     size_t budget = (size_t)((free_b + have) * 0.6);
-    u32 slots = (u32)std::min<size_t>(std::min<u32>(want_rows, 65535u), std::max<size_t>(1, budget / per_slot));  // gridDim.y limit
+    u32 slots = (u32)std::min<size_t>(std::min<u32>(want_rows, c->max_slots), std::max<size_t>(1, budget / per_slot));
     if (slots <= c->slots) return LZANI_OK;
     free_slabs(c);
     HIPCHK(c, hipMalloc(&c->d_dirz, (size_t)slots * c->dir_stride * 4));
@@ -158,10 +159,6 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     if (c->bk_stride) HIPCHK(c, hipMalloc(&c->d_bk, (size_t)slots * c->bk_stride * 4));
     if (c->tw_stride) HIPCHK(c, hipMalloc(&c->d_tw, (size_t)slots * c->tw_stride * 4));
     HIPCHK(c, hipMalloc(&c->d_status, (size_t)slots * 4));
-    if (c->use_tpp) {
-        HIPCHK(c, hipMalloc(&c->d_sdirz, (size_t)slots * c->sdir_stride * 4));
-        HIPCHK(c, hipMalloc(&c->d_sent, (size_t)slots * c->ent_stride * 4));
-    }
     c->slots = slots;
     return LZANI_OK;
 }
@@ -176,7 +173,7 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
     ia.ref_ids = d_ref_ids;
     ia.dirz = c->d_dirz; ia.ent = c->d_ent;
     ia.dir_stride = c->dir_stride; ia.ent_stride = c->ent_stride;
-    ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo; ia.seed = 0; ia.todo = nullptr;
+    ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo; ia.todo = nullptr;
     const u32 nb = 1u << c->geo.dirbits;
     if (c->d_kmL && !c->kmers_ready) {            // per-genome k-mer words, inside the timed index stage
         for (u32 g0 = 0; g0 < c->n; g0 += 32768) {
@@ -218,21 +215,6 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
         hipLaunchKernelGGL(k_idx_buckets, dim3(gx_bkt, rows), dim3(256), 0, c->stream,
                            c->d_dirz, c->d_ent, c->d_bk, c->d_tw, c->dir_stride, c->ent_stride, c->bk_stride, c->tw_stride,
                            nb, c->geo.posbits, ia.todo);
-    if (c->use_tpp) {                             // second index over the msl-mers
-        IdxArgs sa = ia;
-        sa.todo = nullptr;
-        sa.dirz = c->d_sdirz; sa.ent = c->d_sent; sa.dir_stride = c->sdir_stride;
-        sa.mal = c->P.msl; sa.geo = c->sgeo; sa.seed = 1;
-        const u32 snb = 1u << c->sgeo.dirbits;
-        HIPCHK(c, hipMemsetAsync(c->d_sdirz, 0, (size_t)rows * c->sdir_stride * 4, c->stream));
-        const dim3 gs((c->Tmax + 255) / 256, rows);
-        hipLaunchKernelGGL(k_idx_count, gs, dim3(256), 0, c->stream, sa, c->Tmax);
-        hipLaunchKernelGGL(k_idx_scan, dim3(rows), dim3(1024), 0, c->stream, c->d_sdirz, c->sdir_stride, snb, (const u32*)nullptr);
-        hipLaunchKernelGGL(k_idx_fill, gs, dim3(256), 0, c->stream, sa, c->Tmax);
-        hipLaunchKernelGGL(k_idx_sort, dim3((snb + 255) / 256, rows), dim3(256), 0, c->stream,
-                           c->d_sdirz, c->d_sent, c->sdir_stride, c->ent_stride, snb, (const u32*)nullptr, 1);
-        c->tm.index_launches += 4;
-    }
     HIPCHK(c, hipGetLastError());
     c->tm.index_launches += 4;
     return LZANI_OK;
@@ -246,6 +228,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     if (!c->n) return fail(c, LZANI_ERR_STATE, "lzani_run_rows: no genomes set");
     c->tm = lzani_timing{};
     c->kmers_ready = false;                       // recomputed inside every run: it is part of the path's work
+    c->batches_last_run = 0;
     if (n_rows == 0) return LZANI_OK;
     const u64 n_pairs = row_off[n_rows];
     for (u32 k = 0; k < n_rows; ++k) {
@@ -264,33 +247,81 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     int rc = ensure_slabs(c, n_rows);
     if (rc) return rc;
 
+    // Batches of `slots` rows (one index slab per row).  Everything the batches need from the host -- row tables
+    // and the per-XCD work queues of every batch -- is prepared and uploaded before the first launch, so the
+    // batches follow each other on the stream without a host round trip in between.
+    const u32 n_batches = (n_rows + c->slots - 1) / c->slots;
+    c->batches_last_run = n_batches;
+    std::vector<u32> qorder(n_rows);
+    std::vector<u64> qcum((size_t)n_rows + n_batches);
+    std::vector<u32> qb((size_t)n_batches * (NQUEUES + 1));
+    {
+        std::vector<u32> by_size;
+        std::vector<u32> queue[NQUEUES];
+        for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += c->slots) {
+            const u32 rows = std::min(c->slots, n_rows - k0);
+            auto rlen = [&](u32 k) { return row_off[k0 + k + 1] - row_off[k0 + k]; };
+            // rows -> queues: longest row first onto the least loaded queue (equal rows: round robin)
+            by_size.resize(rows);
+            for (u32 k = 0; k < rows; ++k) by_size[k] = k;
+            std::stable_sort(by_size.begin(), by_size.end(), [&](u32 x, u32 y) { return rlen(x) > rlen(y); });
+            u64 load[NQUEUES] = {0};
+            for (auto& q : queue) q.clear();
+            for (u32 k : by_size) {
+                u32 best = 0;
+                for (u32 x = 1; x < NQUEUES; ++x) if (load[x] < load[best]) best = x;
+                queue[best].push_back(k);
+                load[best] += rlen(k);
+            }
+            u32 at = 0;
+            u64 cum = 0;
+            u32* qo = qorder.data() + k0;
+            u64* qc = qcum.data() + k0 + b;
+            qc[0] = 0;
+            for (u32 x = 0; x < NQUEUES; ++x) {
+                qb[(size_t)b * (NQUEUES + 1) + x] = at;
+                for (u32 k : queue[x]) { qo[at] = k; cum += rlen(k); qc[++at] = cum; }
+            }
+            qb[(size_t)b * (NQUEUES + 1) + NQUEUES] = at;
+        }
+    }
+
     DevBuf<u32> d_ref, d_q, d_qorder;
     DevBuf<u64> d_off, d_qcum;
     HIPCHK(c, d_qorder.alloc(n_rows));
-    HIPCHK(c, d_qcum.alloc((size_t)n_rows + 1));
+    HIPCHK(c, d_qcum.alloc(qcum.size()));
     HIPCHK(c, d_ref.alloc(n_rows));
     HIPCHK(c, d_off.alloc((size_t)n_rows + 1));
     HIPCHK(c, hipMemcpyAsync(d_ref, ref_ids, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_off, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_qorder, qorder.data(), qorder.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_qcum, qcum.data(), qcum.size() * 8, hipMemcpyHostToDevice, c->stream));
     if (query_ids) {
         HIPCHK(c, d_q.alloc(n_pairs));
         HIPCHK(c, hipMemcpyAsync(d_q, query_ids, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     }
+    while (c->events.size() < (size_t)4 * n_batches) {        // four stamps per batch, read back after the one sync
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->events.push_back(e);
+    }
 
-    hipDeviceProp_t prop;
-    HIPCHK(c, hipGetDeviceProperties(&prop, c->dev));
     u32 blocks_per_cu = 8;                                   // 8 blocks x 4 waves = 8 waves per SIMD
     if (const char* e = getenv("LZANI_BLOCKS_PER_CU")) blocks_per_cu = (u32)std::max(1, std::min(8, atoi(e)));   // occupancy experiments
-    const u32 max_blocks = (u32)prop.multiProcessorCount * blocks_per_cu;
+    const u32 max_blocks = (u32)c->n_cus * blocks_per_cu;
+    const Params& q = c->P;
+    const bool defp = q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3;
+    std::vector<char> launched(n_batches, 0);
 
-    for (u32 k0 = 0; k0 < n_rows; k0 += c->slots) {
-        u32 rows = std::min(c->slots, n_rows - k0);
-        u64 e0 = row_off[k0], e1 = row_off[k0 + rows];
-        TRACE("batch rows [%u,%u) pairs [%llu,%llu) slots=%u", k0, k0 + rows, (unsigned long long)e0, (unsigned long long)e1, c->slots);
-        HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += c->slots) {
+        const u32 rows = std::min(c->slots, n_rows - k0);
+        const u64 e0 = row_off[k0], e1 = row_off[k0 + rows];
+        hipEvent_t* ev = c->events.data() + (size_t)4 * b;
+        TRACE("batch %u rows [%u,%u) pairs [%llu,%llu) slots=%u", b, k0, k0 + rows, (unsigned long long)e0, (unsigned long long)e1, c->slots);
+        HIPCHK(c, hipEventRecord(ev[0], c->stream));
         rc = build_indexes(c, d_ref + k0, rows);
         if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(c, hipEventRecord(ev[1], c->stream));
         if (e1 > e0) {
             PairArgs pa;
             pa.G = gtab(c);
@@ -301,104 +332,71 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.tw = c->d_tw; pa.tw_stride = c->tw_stride;
             pa.ref_ids = d_ref + k0; pa.row_off = d_off + k0; pa.query_ids = d_q;
             pa.out = d_out; pa.cursor = c->d_cursor;
-            // rows -> queues: longest row first onto the least loaded queue (equal rows: round robin)
-            std::vector<u32> by_size(rows);
-            for (u32 k = 0; k < rows; ++k) by_size[k] = k;
-            std::stable_sort(by_size.begin(), by_size.end(), [&](u32 x, u32 y) {
-                return row_off[k0 + x + 1] - row_off[k0 + x] > row_off[k0 + y + 1] - row_off[k0 + y]; });
-            std::vector<std::vector<u32>> queue(NQUEUES);
-            u64 load[NQUEUES] = {0};
-            for (u32 k : by_size) {
-                u32 best = 0;
-                for (u32 x = 1; x < NQUEUES; ++x) if (load[x] < load[best]) best = x;
-                queue[best].push_back(k);
-                load[best] += row_off[k0 + k + 1] - row_off[k0 + k];
-            }
-            std::vector<u32> qorder; std::vector<u64> qcum(1, 0);
-            for (u32 x = 0; x < NQUEUES; ++x) {
-                pa.qb[x] = (u32)qorder.size();
-                for (u32 k : queue[x]) { qorder.push_back(k); qcum.push_back(qcum.back() + (row_off[k0 + k + 1] - row_off[k0 + k])); }
-            }
-            pa.qb[NQUEUES] = (u32)qorder.size();
-            HIPCHK(c, hipMemcpyAsync(d_qorder, qorder.data(), qorder.size() * 4, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(d_qcum, qcum.data(), qcum.size() * 8, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));       // the host vectors die at the end of this scope
-            pa.qorder = d_qorder; pa.qcum = d_qcum;
-            HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, NQUEUES * sizeof(unsigned long long), c->stream));
-            u64 waves = e1 - e0;
-            u32 blocks = (u32)std::min<u64>((waves + 3) / 4, max_blocks);
-            HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-            const Params& q = c->P;
-            const bool defp = q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3;
-            const dim3 gd(blocks), bd(256);
+            pa.qorder = d_qorder + k0; pa.qcum = d_qcum + k0 + b;
+            for (int x = 0; x <= NQUEUES; ++x) pa.qb[x] = qb[(size_t)b * (NQUEUES + 1) + x];
             pa.reg_out = rs ? rs->d_regions : nullptr; pa.reg_count = rs ? rs->d_count : nullptr; pa.reg_cap = rs ? rs->capacity : 0;
-            if (c->use_tpp && !rs) {
-                TppArgs ta;
-                ta.pa = pa; ta.sdirz = c->d_sdirz; ta.sent = c->d_sent;
-                ta.sdir_stride = c->sdir_stride; ta.sent_stride = c->ent_stride; ta.sgeo = c->sgeo;
-                const u64 lanes = e1 - e0;
-                const dim3 tg((u32)std::min<u64>((lanes + 255) / 256, max_blocks));
-                if (c->all_nfree && defp) hipLaunchKernelGGL((k_pairs_tpp<true, true>), tg, bd, 0, c->stream, ta);
-                else if (c->all_nfree) hipLaunchKernelGGL((k_pairs_tpp<true, false>), tg, bd, 0, c->stream, ta);
-                else if (defp) hipLaunchKernelGGL((k_pairs_tpp<false, true>), tg, bd, 0, c->stream, ta);
-                else hipLaunchKernelGGL((k_pairs_tpp<false, false>), tg, bd, 0, c->stream, ta);
-            } else {
+            HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, NQUEUES * sizeof(unsigned long long), c->stream));
+            const u64 waves = e1 - e0;
+            const dim3 gd((u32)std::min<u64>((waves + 3) / 4, max_blocks)), bd(256);
+            HIPCHK(c, hipEventRecord(ev[2], c->stream));
 #define LZ_PAIRS(F, N, D, A, B) hipLaunchKernelGGL((k_pairs<F, N, D, A, B>), gd, bd, 0, c->stream, pa)
-                const bool fast = c->d_kmL != nullptr, tw = pa.tw != nullptr, nf = c->all_nfree;
-                if (rs) {                                   // alignment output: one generic instantiation per index form
-                    if (!fast) LZ_PAIRS(false, false, false, true, false);
-                    else if (tw) LZ_PAIRS(true, false, false, true, true);
-                    else LZ_PAIRS(true, false, false, true, false);
-                } else if (!fast) LZ_PAIRS(false, false, false, false, false);
-                else if (tw) {
-                    if (nf && defp) LZ_PAIRS(true, true, true, false, true);
-                    else if (nf) LZ_PAIRS(true, true, false, false, true);
-                    else if (defp) LZ_PAIRS(true, false, true, false, true);
-                    else LZ_PAIRS(true, false, false, false, true);
-                } else {
-                    if (nf && defp) LZ_PAIRS(true, true, true, false, false);
-                    else if (nf) LZ_PAIRS(true, true, false, false, false);
-                    else if (defp) LZ_PAIRS(true, false, true, false, false);
-                    else LZ_PAIRS(true, false, false, false, false);
-                }
-#undef LZ_PAIRS
+            const bool fast = c->d_kmL != nullptr, tw = pa.tw != nullptr, nf = c->all_nfree;
+            if (rs) {                                   // alignment output: one generic instantiation per index form
+                if (!fast) LZ_PAIRS(false, false, false, true, false);
+                else if (tw) LZ_PAIRS(true, false, false, true, true);
+                else LZ_PAIRS(true, false, false, true, false);
+            } else if (!fast) LZ_PAIRS(false, false, false, false, false);
+            else if (tw) {
+                if (nf && defp) LZ_PAIRS(true, true, true, false, true);
+                else if (nf) LZ_PAIRS(true, true, false, false, true);
+                else if (defp) LZ_PAIRS(true, false, true, false, true);
+                else LZ_PAIRS(true, false, false, false, true);
+            } else {
+                if (nf && defp) LZ_PAIRS(true, true, true, false, false);
+                else if (nf) LZ_PAIRS(true, true, false, false, false);
+                else if (defp) LZ_PAIRS(true, false, true, false, false);
+                else LZ_PAIRS(true, false, false, false, false);
             }
+#undef LZ_PAIRS
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            HIPCHK(c, hipEventRecord(ev[3], c->stream));
+            launched[b] = 1;
             c->tm.pair_launches += 1;
         }
-        if (trace_on()) { HIPCHK(c, hipEventSynchronize(c->ev[1])); TRACE("index built"); }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        TRACE("pairs done");
+        c->tm.pairs += e1 - e0;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));       // the one host wait of the call
+    TRACE("pairs done");
 #ifdef LZANI_STAMPS
-        {
-            unsigned long long acc[8];
-            HIPCHK(c, hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_stamp_acc), sizeof acc));
-            unsigned long long tot = 0;
-            for (int k = 0; k < 8; ++k) tot += acc[k];
-            fprintf(stderr, "[lzani stamps] pairs=%llu total_cycles/pair=%.0f shares:", (unsigned long long)(e1 - e0), (double)tot / (double)(e1 - e0));
-            const char* nm[8] = {"setup", "anchors", "seeds", "event", "-", "ext_fwd", "tail", "post_ballot"};
-            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)acc[k] / (double)tot);
-            fprintf(stderr, "\n");
-            unsigned long long z[8] = {0};
-            HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof z));
-        }
+    {
+        unsigned long long acc[8];
+        HIPCHK(c, hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_stamp_acc), sizeof acc));
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; ++k) tot += acc[k];
+        fprintf(stderr, "[lzani stamps] pairs=%llu total_cycles/pair=%.0f shares:", (unsigned long long)n_pairs, (double)tot / (double)n_pairs);
+        const char* nm[8] = {"setup", "anchors", "seeds", "event", "-", "ext_fwd", "tail", "post_ballot"};
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)acc[k] / (double)tot);
+        fprintf(stderr, "\n");
+        unsigned long long z[8] = {0};
+        HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof z));
+    }
 #endif
-        int trip = 0;
-        HIPCHK(c, hipMemcpyFromSymbol(&trip, HIP_SYMBOL(g_guard_trip), sizeof(int)));
-        if (trip) {
-            int zero = 0;
-            HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_guard_trip), &zero, sizeof(int)));
-            return fail(c, LZANI_ERR_DEVICE, "pair kernel: loop guard " + std::to_string(trip) + " tripped (corrupt index or text)");
-        }
+    int trip = 0;
+    HIPCHK(c, hipMemcpyFromSymbol(&trip, HIP_SYMBOL(g_guard_trip), sizeof(int)));
+    if (trip) {
+        int zero = 0;
+        HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_guard_trip), &zero, sizeof(int)));
+        return fail(c, LZANI_ERR_DEVICE, "pair kernel: loop guard " + std::to_string(trip) + " tripped (corrupt index or text)");
+    }
+    for (u32 b = 0; b < n_batches; ++b) {
+        hipEvent_t* ev = c->events.data() + (size_t)4 * b;
         float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, ev[0], ev[1]));
         c->tm.index_ms += ms;
-        if (e1 > e0) {
-            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+        if (launched[b]) {
+            HIPCHK(c, hipEventElapsedTime(&ms, ev[2], ev[3]));
             c->tm.pairs_ms += ms;
         }
-        c->tm.pairs += e1 - e0;
     }
     return LZANI_OK;
 }
@@ -406,6 +404,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 }  // namespace
 
 extern "C" {
+
+static void comm_release(lzani_ctx* c);      // lzani_multi.h
 
 void lzani_default_params(lzani_params* p)
 {
@@ -428,7 +428,11 @@ int lzani_create(const lzani_params* p, int device_id, lzani_ctx** out)
     c->dev = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
               hipMalloc(&c->d_cursor, NQUEUES * sizeof(unsigned long long)) == hipSuccess;
-    for (int k = 0; ok && k < 4; ++k) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
+    if (ok) {
+        hipDeviceProp_t prop;
+        ok = hipGetDeviceProperties(&prop, device_id) == hipSuccess;
+        if (ok) c->n_cus = prop.multiProcessorCount;
+    }
     if (!ok) { lzani_destroy(c); return LZANI_ERR_DEVICE; }
     *out = c;
     return LZANI_OK;
@@ -438,10 +442,11 @@ void lzani_destroy(lzani_ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->dev);
+    comm_release(c);
     free_genomes(c);
     free_slabs(c);
     hipFree(c->d_cursor);
-    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    for (auto& e : c->events) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -489,6 +494,7 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
         HIPCHK(c, hipMalloc(&c->d_kmL, total_nm * 64 * 4));
         HIPCHK(c, hipMalloc(&c->d_kmS, total_nm * 64 * 4));
     }
+    choose_index_form(c);
     // stage the codes through one pinned-size host buffer per chunk of genomes
     {
         std::vector<uint8_t> stage;
@@ -592,6 +598,19 @@ int lzani_get_timing(const lzani_ctx* c, lzani_timing* t)
     return LZANI_OK;
 }
 
+int lzani_get_layout(const lzani_ctx* c, lzani_layout_info* o)
+{
+    if (!c || !o) return LZANI_ERR_ARG;
+    o->key_bits = c->geo.kb; o->dir_bits = c->geo.dirbits; o->pos_bits = c->geo.posbits; o->tag_mask = c->geo.tagmask;
+    o->kmer_words = c->d_kmL != nullptr;
+    o->bucket_table = c->bk_stride != 0; o->tag_words = c->tw_stride != 0;
+    o->n_free = c->all_nfree;
+    o->slots = c->slots; o->batches_last_run = c->batches_last_run;
+    o->bytes_per_slot = 4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride);
+    o->bytes_genomes = c->total_nm * (16 + 8) + (c->d_kmL ? c->total_nm * 64 * 8 : 0);
+    return LZANI_OK;
+}
+
 int lzani_debug_get_index(lzani_ctx* c, uint32_t id, uint64_t* t2, uint64_t* nm, uint32_t* dirz,
                           uint32_t* ent, uint32_t* n_ent, uint32_t* geom)
 {
@@ -621,3 +640,5 @@ int lzani_debug_get_index(lzani_ctx* c, uint32_t id, uint64_t* t2, uint64_t* nm,
 }
 
 }  // extern "C"
+
+#include "lzani_multi.h"

@@ -85,9 +85,8 @@ struct IdxArgs {
     u32* dirz;               // slots * dir_stride
     u32* ent;                // slots * ent_stride
     u64 dir_stride, ent_stride;
-    int mal, mrd;            // mal = the k of this index (min_anchor_len, or min_seed_len for the seed index)
+    int mal, mrd;
     IndexGeom geo;
-    int seed;                // 1: index of the msl-mers (key words from kmS, mixed here)
     const u32* todo;         // per slot: nonzero = this slot is (re)built by the global-atomics kernels; nullptr = all
 };
 
@@ -99,9 +98,9 @@ __device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, 
     u64 o = a.G.nmoff[g];
     u64 h;
     if (a.G.kmL) {
-        u32 v = a.seed ? a.G.kmS[64 * o + p] : a.G.kmL[64 * o + p];
+        u32 v = a.G.kmL[64 * o + p];
         if (v == KM_INVALID) return false;
-        h = a.seed ? mix_key(v, a.geo.kb) : (u64)v;
+        h = (u64)v;
     } else {
         TextView R = ref_view(a.G.t2 + 2 * o, a.G.nm + o, a.G.L[g], a.mrd, false);
         u64 key;

@@ -4,7 +4,6 @@
 //                 per-XCD work queues (replaces prepare_data + parse + calc_stats,
 //                 parser.cpp:37-50, 482-716, 734-783, and the worker loop of do_matching,
 //                 lz_matcher.cpp:192-269); instantiations FAST/NFREE/DEFP/ALN/BK, see the kernel
-//   k_pairs_tpp   thread-per-pair variant of the same machine (opt-in, LZANI_KERNEL=tpp; slower)
 #pragma once
 
 namespace lzani {
@@ -444,69 +443,6 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamp_acc[k], w.acc[k]);
 #endif
         int* o = a.out + 3 * e;          // every lane stores the same wave-uniform values
-        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_pairs_tpp: thread-per-pair variant.  Every lane owns one directed pair and runs the same pair
-// machine with the lane-serial policy (LaneWave, lzani_core.h): 64 independent pairs per wavefront,
-// no cross-lane traffic, the close seeds come from a second (msl) index of the reference.  Lanes pull
-// their pairs from the per-XCD queues one ticket each, so a finished lane never waits for its wave.
-// ------------------------------------------------------------------------------------------
-struct TppArgs {
-    PairArgs pa;
-    const u32* sdirz;        // seed index slabs, like dirz/ent
-    const u32* sent;
-    u64 sdir_stride, sent_stride;
-    IndexGeom sgeo;
-};
-
-template <bool NFREE, bool DEFP>
-__global__ void __launch_bounds__(256) k_pairs_tpp(TppArgs ta)
-{
-    const PairArgs& a = ta.pa;
-    const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
-    u32 qx = xcc_id() % NQUEUES, dry = 0;
-    for (;;) {
-        const unsigned long long t = atomicAdd(&a.cursor[qx], 1ULL);     // one ticket per lane
-        const u32 rb = a.qb[qx], re = a.qb[qx + 1];
-        const u64 tk = a.qcum[rb] + t;
-        if (tk >= a.qcum[re]) {
-            if (++dry >= NQUEUES) break;
-            qx = (qx + 1) % NQUEUES;
-            continue;
-        }
-        u32 lo = rb, hi = re;
-        while (hi - lo > 1) {
-            u32 mid = (lo + hi) >> 1;
-            if (a.qcum[mid] <= tk) lo = mid; else hi = mid;
-        }
-        const u32 slot = a.qorder[lo];
-        const u32 r = a.ref_ids[slot];
-        const u32 j = (u32)(tk - a.qcum[lo]);
-        const u64 e = a.row_off[slot] + j;
-        const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
-        const int Lr = a.G.L[r], Lq = a.G.L[q];
-        const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
-        const int T = ref_text_len(Lr, Pk.mrd), D = Lq + Pk.mrd;
-        IndexView iv, sv;
-        iv.dirz = a.dirz + slot * a.dir_stride;
-        iv.ent = a.ent + slot * a.ent_stride;
-        iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
-        iv.bk = nullptr; sv.bk = nullptr;
-        iv.tw = nullptr; sv.tw = nullptr;
-        sv.dirz = ta.sdirz + slot * ta.sdir_stride;
-        sv.ent = ta.sent + slot * ta.sent_stride;
-        sv.kb = ta.sgeo.kb; sv.dirbits = ta.sgeo.dirbits; sv.posbits = ta.sgeo.posbits; sv.tagmask = ta.sgeo.tagmask;
-        const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
-        LaneWave w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
-                   qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, sv,
-                   a.G.kmL + 64 * qo, a.G.kmS + 64 * qo};
-        PairMachine<LaneWave> m(w, Pk, T, D);
-        int res[3];
-        m.run(res);
-        int* o = a.out + 3 * e;
         o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
     }
 }

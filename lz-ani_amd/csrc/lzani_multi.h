@@ -1,0 +1,357 @@
+// lzani_multi.h -- the multi-GPU layer of the C-ABI (include/lzani.h, "sharding over GPUs").  Included by
+// lzani_hip.hip only, after the single-GPU entry points it builds on.
+//
+// What shards is the reference's own work unit, the reference ROW (one index build, many queries;
+// /root/reference/src/lz_matcher.cpp:196-255): rows are independent, the packed genome set is replicated on
+// every GPU (10k x 40 kbp = 0.3 GB of text + 6.4 GB of k-mer words against 288 GB of HBM), and the only
+// exchange is ONE gather of the per-pair int32[3] records after the compute -- RCCL over xGMI.
+//
+//   lzani_partition_rows / lzani_row_costs   rows -> shards: cyclic for equal-cost (dense) rows, greedy
+//                                            longest-processing-time for the ragged rows of a kmer-db filter
+//   lzani_comm_*                             one process per GPU (torchrun, MPI...): ncclCommInitRank from a
+//                                            unique id the caller distributes, ncclAllGather of padded shards
+//                                            or grouped ncclSend/ncclRecv of ragged shards to a root
+//   lzani_group_*                            one process, n GPUs (the `lz-ani --gpus n` host binary): a context
+//                                            per device on its own host thread, ncclCommInitAll, grouped
+//                                            ncclSend/ncclRecv to device 0, a scatter kernel into the caller's
+//                                            CSR order and ONE device-to-host copy
+#pragma once
+#include <rccl/rccl.h>
+
+#include <numeric>
+#include <thread>
+
+namespace {
+
+#define RCCLCHK(c, call)                                                                              \
+    do {                                                                                              \
+        ncclResult_t r_ = (call);                                                                     \
+        if (r_ != ncclSuccess)                                                                        \
+            return fail(c, LZANI_ERR_DEVICE, std::string(#call) + ": " + ncclGetErrorString(r_));     \
+    } while (0)
+
+// Rows of a gathered buffer (shard order) -> the caller's CSR order.  One block per row.
+__global__ void k_scatter_rows(const int* __restrict__ src, int* __restrict__ dst, const u64* __restrict__ src_off,
+                               const u64* __restrict__ dst_off, const u64* __restrict__ count)
+{
+    const u64 s = 3 * src_off[blockIdx.x], d = 3 * dst_off[blockIdx.x], n = 3 * count[blockIdx.x];
+    for (u64 k = threadIdx.x; k < n; k += blockDim.x) dst[d + k] = src[s + k];
+}
+
+}  // namespace
+
+struct lzani_group {
+    std::vector<lzani_ctx*> ctx;
+    std::vector<int> devs;
+    std::vector<ncclComm_t> comms;      // one per device; empty when the group has one device or is a rehearsal
+    bool rehearsal = false;             // the same device listed more than once: shards move by device copies
+    std::string err;
+    double gather_ms = 0;
+};
+
+static void comm_release(lzani_ctx* c)
+{
+    if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+}
+
+extern "C" {
+
+// ---- rows -> shards ---------------------------------------------------------------------------------
+int lzani_row_costs(uint32_t n_rows, const uint32_t* ref_ids, const uint64_t* row_off, const uint32_t* query_ids,
+                    uint32_t n, const uint32_t* len, uint64_t* cost)
+{
+    if (!ref_ids || !row_off || !len || !cost) return LZANI_ERR_ARG;
+    u64 total = 0;
+    if (!query_ids) for (u32 g = 0; g < n; ++g) total += len[g];
+    for (u32 k = 0; k < n_rows; ++k) {
+        if (ref_ids[k] >= n) return LZANI_ERR_ARG;
+        u64 c = (u64)LZANI_ROW_COST_REF_WEIGHT * len[ref_ids[k]];
+        if (!query_ids) c += total - len[ref_ids[k]];
+        else
+            for (u64 e = row_off[k]; e < row_off[k + 1]; ++e) {
+                if (query_ids[e] >= n) return LZANI_ERR_ARG;
+                c += len[query_ids[e]];
+            }
+        cost[k] = c;
+    }
+    return LZANI_OK;
+}
+
+int lzani_partition_rows(uint32_t n_rows, const uint64_t* row_cost, uint32_t n_parts, uint32_t* part_of_row)
+{
+    if (!n_parts || (n_rows && !part_of_row)) return LZANI_ERR_ARG;
+    if (!row_cost) {                                          // equal rows: cyclic in the given (length-descending) order
+        for (u32 k = 0; k < n_rows; ++k) part_of_row[k] = k % n_parts;
+        return LZANI_OK;
+    }
+    // greedy LPT: heaviest row first onto the least loaded shard (ties: earlier row, lower shard) -- the 4/3 rule
+    std::vector<u32> order(n_rows);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return row_cost[a] > row_cost[b]; });
+    typedef std::pair<u64, u32> Load;                          // (load, shard): a min-heap
+    std::vector<Load> heap;
+    for (u32 p = 0; p < n_parts; ++p) heap.emplace_back(0, p);
+    auto cmp = [](const Load& a, const Load& b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    for (u32 k : order) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        Load& l = heap.back();
+        part_of_row[k] = l.second;
+        l.first += row_cost[k];
+        std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    return LZANI_OK;
+}
+
+// ---- one process per GPU ------------------------------------------------------------------------------
+int lzani_comm_unique_id(uint8_t* id)
+{
+    if (!id) return LZANI_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == LZANI_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return LZANI_ERR_DEVICE;
+    memcpy(id, &u, sizeof u);
+    return LZANI_OK;
+}
+
+int lzani_comm_init(lzani_ctx* c, uint32_t n_ranks, uint32_t rank, const uint8_t* id)
+{
+    if (!c) return LZANI_ERR_ARG;
+    if (!id || !n_ranks || rank >= n_ranks) return fail(c, LZANI_ERR_ARG, "lzani_comm_init: bad rank / id");
+    if (c->comm) return fail(c, LZANI_ERR_STATE, "lzani_comm_init: communicator exists already");
+    HIPCHK(c, hipSetDevice(c->dev));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclComm_t comm = nullptr;
+    RCCLCHK(c, ncclCommInitRank(&comm, (int)n_ranks, u, (int)rank));
+    c->comm = comm; c->n_ranks = n_ranks; c->rank = rank;
+    return LZANI_OK;
+}
+
+int lzani_comm_allgather(lzani_ctx* c, const void* d_send, void* d_recv, uint64_t n_results)
+{
+    if (!c) return LZANI_ERR_ARG;
+    if (!c->comm) return fail(c, LZANI_ERR_STATE, "lzani_comm_allgather: no communicator (lzani_comm_init)");
+    if (n_results && (!d_send || !d_recv)) return fail(c, LZANI_ERR_ARG, "lzani_comm_allgather: null buffer");
+    HIPCHK(c, hipSetDevice(c->dev));
+    RCCLCHK(c, ncclAllGather(d_send, d_recv, (size_t)n_results * 3, ncclInt32, (ncclComm_t)c->comm, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LZANI_OK;
+}
+
+int lzani_comm_gatherv(lzani_ctx* c, const void* d_send, void* d_recv, const uint64_t* counts, uint32_t root)
+{
+    if (!c) return LZANI_ERR_ARG;
+    if (!c->comm) return fail(c, LZANI_ERR_STATE, "lzani_comm_gatherv: no communicator (lzani_comm_init)");
+    if (!counts || root >= c->n_ranks) return fail(c, LZANI_ERR_ARG, "lzani_comm_gatherv: bad argument");
+    HIPCHK(c, hipSetDevice(c->dev));
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    if (c->rank == root) {
+        if (!d_recv) return fail(c, LZANI_ERR_ARG, "lzani_comm_gatherv: null receive buffer on the root");
+        u64 off = 0;
+        for (u32 p = 0; p < root; ++p) off += counts[p];
+        if (counts[root] && (int*)d_recv + 3 * off != d_send)          // the root's own shard
+            HIPCHK(c, hipMemcpyAsync((int*)d_recv + 3 * off, d_send, counts[root] * 12, hipMemcpyDeviceToDevice, c->stream));
+        ncclResult_t r = ncclGroupStart();
+        off = 0;
+        for (u32 p = 0; p < c->n_ranks && r == ncclSuccess; ++p) {
+            if (p != root && counts[p]) r = ncclRecv((int*)d_recv + 3 * off, (size_t)counts[p] * 3, ncclInt32, (int)p, comm, c->stream);
+            off += counts[p];
+        }
+        const ncclResult_t r2 = ncclGroupEnd();
+        RCCLCHK(c, r);
+        RCCLCHK(c, r2);
+    } else if (counts[c->rank])
+        RCCLCHK(c, ncclSend(d_send, (size_t)counts[c->rank] * 3, ncclInt32, (int)root, comm, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LZANI_OK;
+}
+
+// ---- one process, n GPUs ------------------------------------------------------------------------------
+static int gfail(lzani_group* g, int code, const std::string& msg) { if (g) g->err = msg; return code; }
+
+void lzani_group_destroy(lzani_group* g)
+{
+    if (!g) return;
+    for (auto cm : g->comms) if (cm) ncclCommDestroy(cm);
+    for (auto c : g->ctx) lzani_destroy(c);
+    delete g;
+}
+
+const char* lzani_group_last_error(const lzani_group* g) { return g ? g->err.c_str() : "null group"; }
+
+int lzani_group_create(const lzani_params* p, uint32_t n_devices, const int* device_ids, lzani_group** out)
+{
+    if (!p || !out || !n_devices || !device_ids) return LZANI_ERR_ARG;
+    *out = nullptr;
+    lzani_group* g = new (std::nothrow) lzani_group();
+    if (!g) return LZANI_ERR_NOMEM;
+    g->devs.assign(device_ids, device_ids + n_devices);
+    for (u32 d = 0; d < n_devices; ++d) {
+        lzani_ctx* c = nullptr;
+        int rc = lzani_create(p, device_ids[d], &c);
+        if (rc != LZANI_OK) { lzani_group_destroy(g); return rc; }
+        g->ctx.push_back(c);
+    }
+    std::vector<int> sorted(g->devs);
+    std::sort(sorted.begin(), sorted.end());
+    g->rehearsal = std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end();
+    if (n_devices > 1 && !g->rehearsal) {
+        g->comms.assign(n_devices, nullptr);
+        ncclResult_t r = ncclCommInitAll(g->comms.data(), (int)n_devices, g->devs.data());
+        if (r != ncclSuccess) {
+            g->comms.clear();
+            lzani_group_destroy(g);
+            return LZANI_ERR_DEVICE;
+        }
+    }
+    *out = g;
+    return LZANI_OK;
+}
+
+int lzani_group_set_genomes(lzani_group* g, uint32_t n, const uint8_t* const* codes, const uint32_t* len)
+{
+    if (!g) return LZANI_ERR_ARG;
+    std::vector<int> rc(g->ctx.size(), LZANI_OK);
+    std::vector<std::thread> th;
+    auto one = [&](size_t d) { rc[d] = lzani_set_genomes(g->ctx[d], n, codes, len); };
+    for (size_t d = 1; d < g->ctx.size(); ++d) th.emplace_back(one, d);
+    one(0);
+    for (auto& t : th) t.join();
+    for (size_t d = 0; d < g->ctx.size(); ++d)
+        if (rc[d] != LZANI_OK) return gfail(g, rc[d], "device " + std::to_string(g->devs[d]) + ": " + lzani_last_error(g->ctx[d]));
+    return LZANI_OK;
+}
+
+int lzani_group_run_rows(lzani_group* g, uint32_t n_rows, const uint32_t* ref_ids, const uint64_t* row_off,
+                         const uint32_t* query_ids, lzani_result* out)
+{
+    if (!g) return LZANI_ERR_ARG;
+    if (!ref_ids || !row_off) return gfail(g, LZANI_ERR_ARG, "lzani_group_run_rows: null argument");
+    const u32 nd = (u32)g->ctx.size();
+    const u64 n_pairs = n_rows ? row_off[n_rows] : 0;
+    if (n_pairs && !out) return gfail(g, LZANI_ERR_ARG, "lzani_group_run_rows: null output");
+    g->gather_ms = 0;
+    lzani_ctx* c0 = g->ctx[0];
+    if (!c0->n) return gfail(g, LZANI_ERR_STATE, "lzani_group_run_rows: no genomes set");
+    for (u32 k = 0; k < n_rows; ++k)
+        if (ref_ids[k] >= c0->n || row_off[k + 1] < row_off[k]) return gfail(g, LZANI_ERR_ARG, "lzani_group_run_rows: bad row table");
+    if (query_ids)
+        for (u64 e = 0; e < n_pairs; ++e) if (query_ids[e] >= c0->n) return gfail(g, LZANI_ERR_ARG, "lzani_group_run_rows: query id out of range");
+
+    // rows -> devices
+    std::vector<u32> part(n_rows);
+    {
+        std::vector<u64> cost;
+        if (query_ids) {
+            std::vector<u32> len(c0->L.begin(), c0->L.end());
+            cost.resize(n_rows);
+            int rc = lzani_row_costs(n_rows, ref_ids, row_off, query_ids, c0->n, len.data(), cost.data());
+            if (rc != LZANI_OK) return gfail(g, rc, "lzani_group_run_rows: row costs");
+        }
+        lzani_partition_rows(n_rows, query_ids ? cost.data() : nullptr, nd, part.data());
+    }
+    struct Shard { std::vector<u32> rows, ref, q; std::vector<u64> off; u64 base = 0; };
+    std::vector<Shard> sh(nd);
+    for (auto& s : sh) s.off.push_back(0);
+    for (u32 k = 0; k < n_rows; ++k) {
+        Shard& s = sh[part[k]];
+        s.rows.push_back(k);
+        s.ref.push_back(ref_ids[k]);
+        if (query_ids) s.q.insert(s.q.end(), query_ids + row_off[k], query_ids + row_off[k + 1]);
+        s.off.push_back(s.off.back() + (row_off[k + 1] - row_off[k]));
+    }
+    for (u32 d = 1; d < nd; ++d) sh[d].base = sh[d - 1].base + sh[d - 1].off.back();
+
+    // device 0 holds the gathered buffer (its own shard is written in place) and the CSR-ordered copy
+    HIPCHK(c0, hipSetDevice(c0->dev));
+    DevBuf<int> d_all, d_final;
+    if (hipMalloc(&d_all.p, std::max<u64>(n_pairs, 1) * 12) != hipSuccess || hipMalloc(&d_final.p, std::max<u64>(n_pairs, 1) * 12) != hipSuccess)
+        return gfail(g, LZANI_ERR_NOMEM, "lzani_group_run_rows: result buffers on device 0");
+    std::vector<int*> d_shard(nd, nullptr);
+    d_shard[0] = d_all.p;
+    std::vector<int> rc(nd, LZANI_OK);
+    auto one = [&](u32 d) {
+        lzani_ctx* c = g->ctx[d];
+        if (sh[d].ref.empty()) { c->tm = lzani_timing{}; return; }       // no row for this device
+        if (d) {
+            if (hipSetDevice(c->dev) != hipSuccess || hipMalloc(&d_shard[d], std::max<u64>(sh[d].off.back(), 1) * 12) != hipSuccess) { rc[d] = LZANI_ERR_NOMEM; return; }
+        }
+        rc[d] = lzani_run_rows_device(c, (u32)sh[d].ref.size(), sh[d].ref.data(), sh[d].off.data(),
+                                      query_ids ? sh[d].q.data() : nullptr, d_shard[d]);
+    };
+    {
+        std::vector<std::thread> th;
+        for (u32 d = 1; d < nd; ++d) th.emplace_back(one, d);
+        one(0);
+        for (auto& t : th) t.join();
+    }
+    int ret = LZANI_OK;
+    for (u32 d = 0; d < nd && ret == LZANI_OK; ++d)
+        if (rc[d] != LZANI_OK) ret = gfail(g, rc[d], "device " + std::to_string(g->devs[d]) + ": " + lzani_last_error(g->ctx[d]));
+
+    // the gather: every peer's shard to device 0 (grouped ncclSend / ncclRecv over xGMI)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ret == LZANI_OK) {
+        hipSetDevice(c0->dev);
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, c0->stream);
+        if (!g->comms.empty()) {
+            ncclResult_t r = ncclGroupStart();
+            for (u32 d = 1; d < nd && r == ncclSuccess; ++d) {
+                const size_t cnt = (size_t)sh[d].off.back() * 3;
+                if (!cnt) continue;
+                hipSetDevice(g->ctx[d]->dev);
+                r = ncclSend(d_shard[d], cnt, ncclInt32, 0, g->comms[d], g->ctx[d]->stream);
+                hipSetDevice(c0->dev);
+                if (r == ncclSuccess) r = ncclRecv(d_all.p + 3 * sh[d].base, cnt, ncclInt32, (int)d, g->comms[0], c0->stream);
+            }
+            ncclResult_t r2 = ncclGroupEnd();
+            if (r == ncclSuccess) r = r2;
+            if (r != ncclSuccess) ret = gfail(g, LZANI_ERR_DEVICE, std::string("RCCL gather: ") + ncclGetErrorString(r));
+        } else {
+            for (u32 d = 1; d < nd; ++d)                         // rehearsal on one device: plain device copies
+                if (sh[d].off.back() && hipMemcpyAsync(d_all.p + 3 * sh[d].base, d_shard[d], sh[d].off.back() * 12, hipMemcpyDeviceToDevice, c0->stream) != hipSuccess)
+                    ret = gfail(g, LZANI_ERR_DEVICE, "device copy of a shard failed");
+        }
+    }
+    if (ret == LZANI_OK && n_rows) {
+        // shard order -> the caller's CSR order on device 0, then the one device-to-host copy
+        std::vector<u64> tab(3 * (size_t)n_rows);
+        u32 at = 0;
+        for (u32 d = 0; d < nd; ++d)
+            for (size_t i = 0; i < sh[d].rows.size(); ++i, ++at) {
+                tab[at] = sh[d].base + sh[d].off[i];
+                tab[n_rows + at] = row_off[sh[d].rows[i]];
+                tab[2 * (size_t)n_rows + at] = sh[d].off[i + 1] - sh[d].off[i];
+            }
+        DevBuf<u64> d_tab;
+        hipError_t e = d_tab.alloc(tab.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(d_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c0->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_scatter_rows, dim3(n_rows), dim3(256), 0, c0->stream, d_all.p, d_final.p, d_tab.p, d_tab.p + n_rows, d_tab.p + 2 * (size_t)n_rows);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, c0->stream);
+        if (e == hipSuccess && n_pairs) e = hipMemcpyAsync(out, d_final.p, n_pairs * 12, hipMemcpyDeviceToHost, c0->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
+        for (u32 d = 1; d < nd && e == hipSuccess; ++d) { hipSetDevice(g->ctx[d]->dev); e = hipStreamSynchronize(g->ctx[d]->stream); }
+        if (e != hipSuccess) ret = gfail(g, LZANI_ERR_DEVICE, std::string("gather / copy out: ") + hipGetErrorString(e));
+        else { float ms = 0; hipEventElapsedTime(&ms, e0, e1); g->gather_ms = ms; }
+    }
+    for (u32 d = 1; d < nd; ++d) if (d_shard[d]) { hipSetDevice(g->ctx[d]->dev); hipFree(d_shard[d]); }
+    hipSetDevice(c0->dev);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    return ret;
+}
+
+int lzani_group_get_timing(const lzani_group* g, uint32_t device_index, lzani_timing* t, double* gather_ms)
+{
+    if (!g || device_index >= g->ctx.size() || !t) return LZANI_ERR_ARG;
+    *t = g->ctx[device_index]->tm;
+    if (gather_ms) *gather_ms = g->gather_ms;
+    return LZANI_OK;
+}
+
+}  // extern "C"

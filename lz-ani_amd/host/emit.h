@@ -6,6 +6,7 @@
 // digits as the reference's dragonbox), rounded half-up to `prec` significant digits, then the
 // reference's fixed/exponent layout.  Byte-identical output is the contract (BASELINE config 1).
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <charconv>
 #include <cstdint>
@@ -108,8 +109,52 @@ inline size_t real_to_chars(double val, char* out, int prec)
     return (size_t)(ptr - out);
 }
 
-struct IdResult { uint32_t id; lzani_result r; };
-using ResultRows = std::vector<std::vector<IdResult>>;     // results[ref] sorted by id (lz_matcher.cpp:253-255)
+// The matching stage's output as it leaves the engine: CSR rows, row r = reference r against its queries in
+// ascending id order (the order the reference sorts every results[ref] into, lz_matcher.cpp:253-255).  Dense
+// all2all rows store no query list (row r = every id != r).  12 bytes per directed pair, no per-row vectors.
+struct PairTable {
+    uint32_t n = 0;
+    bool dense = true;
+    std::vector<uint64_t> row_off;          // n + 1
+    std::vector<uint32_t> query_ids;        // filtered runs only
+    std::vector<lzani_result> res;          // CSR-aligned
+
+    void init_dense(uint32_t n_)
+    {
+        n = n_; dense = true; query_ids.clear();
+        row_off.resize((size_t)n + 1);
+        for (uint32_t r = 0; r <= n; ++r) row_off[r] = (uint64_t)r * (n ? n - 1 : 0);
+        res.assign(row_off[n], lzani_result{0, 0, 0});
+    }
+    // rows[r] = query ids of reference r (any order; sorted here)
+    void init_sparse(std::vector<std::vector<uint32_t>>& rows)
+    {
+        n = (uint32_t)rows.size(); dense = false;
+        row_off.assign((size_t)n + 1, 0);
+        for (uint32_t r = 0; r < n; ++r) { std::sort(rows[r].begin(), rows[r].end()); row_off[r + 1] = row_off[r] + rows[r].size(); }
+        query_ids.resize(row_off[n]);
+        for (uint32_t r = 0; r < n; ++r) std::copy(rows[r].begin(), rows[r].end(), query_ids.begin() + (ptrdiff_t)row_off[r]);
+        res.assign(row_off[n], lzani_result{0, 0, 0});
+    }
+    uint64_t row_size(uint32_t r) const { return row_off[r + 1] - row_off[r]; }
+    uint32_t id_at(uint32_t r, uint64_t j) const { return dense ? (uint32_t)j + (j >= r ? 1u : 0u) : query_ids[row_off[r] + j]; }
+    const lzani_result& at(uint32_t r, uint64_t j) const { return res[row_off[r] + j]; }
+    // result of parse(query = id, ref = r), or nullptr when the pair was not computed
+    const lzani_result* find(uint32_t r, uint32_t id) const
+    {
+        if (dense) return id == r || id >= n ? nullptr : &res[row_off[r] + (id < r ? id : id - 1)];
+        auto b = query_ids.begin() + (ptrdiff_t)row_off[r], e = query_ids.begin() + (ptrdiff_t)row_off[r + 1];
+        auto it = std::lower_bound(b, e, id);
+        return (it != e && *it == id) ? &res[(size_t)(it - query_ids.begin())] : nullptr;
+    }
+    // first position of row r whose query id exceeds r
+    uint64_t first_above(uint32_t r) const
+    {
+        if (dense) return r;
+        auto b = query_ids.begin() + (ptrdiff_t)row_off[r], e = query_ids.begin() + (ptrdiff_t)row_off[r + 1];
+        return (uint64_t)(std::upper_bound(b, e, r) - b);
+    }
+};
 
 struct EmitParams {
     std::string out_name, ids_name;
@@ -122,82 +167,122 @@ struct EmitParams {
     int mrd = 40;
 };
 
-inline const IdResult* find_id(const std::vector<IdResult>& row, uint32_t id)
+// ---- one TSV line = one DIRECTION of an unordered pair --------------------------------------------------
+// For the pair {a < b} the stage computed X = parse(query b, ref a) and Y = parse(query a, ref b).  A line
+// describes one of them ("own") with the other ("rev") supplying the reference-side coverage; the two lines
+// of a pair share tani.  All ratios are IEEE double divisions of exact integers, as in the reference
+// (lz_matcher.cpp:434-447), so equal integers give byte-equal text.
+struct Direction {
+    uint32_t qidx, ridx, qlen, rlen;
+    const std::string *qname, *rname;
+    int32_t nt_match, nt_mismatch, num_alns;
+    double tani, gani, ani, qcov, rcov;
+};
+
+inline Direction make_direction(const std::vector<Genome>& g, const std::vector<uint32_t>& len, uint32_t q, uint32_t r,
+                                const lzani_result& own, const lzani_result& rev, double tani)
 {
-    auto it = std::lower_bound(row.begin(), row.end(), id, [](const IdResult& a, uint32_t v) { return a.id < v; });
-    return (it != row.end() && it->id == id) ? &*it : nullptr;
+    Direction d;
+    d.qidx = q; d.ridx = r; d.qlen = len[q]; d.rlen = len[r];
+    d.qname = &g[q].name; d.rname = &g[r].name;
+    d.nt_match = own.sym_in_matches; d.nt_mismatch = own.sym_in_literals; d.num_alns = own.no_components;
+    const int32_t aligned = own.sym_in_matches + own.sym_in_literals, aligned_rev = rev.sym_in_matches + rev.sym_in_literals;
+    d.tani = tani;
+    d.gani = (double)own.sym_in_matches / d.qlen;
+    d.ani = aligned != 0 ? (double)own.sym_in_matches / aligned : 0;
+    d.qcov = (double)aligned / d.qlen;
+    d.rcov = (double)aligned_rev / d.rlen;
+    return d;
 }
 
-// One reference row -> text (lz_matcher.cpp:400-562)
-inline void format_row(const std::vector<Genome>& g, const ResultRows& results, const EmitParams& ep, uint32_t ref_id,
-                       std::string& out)
-{
-    const double mult = ep.in_percent ? 100 : 1;
+struct LineOut {
+    std::string& s;
     char num[64];
-    auto put_u = [&](uint64_t v, char sep) { out.append(num, uint_to_chars(v, num)); out.push_back(sep); };
-    auto put_i = [&](int64_t v, char sep) { if (v < 0) { out.push_back('-'); v = -v; } put_u((uint64_t)v, sep); };
-    auto put_r = [&](double v, int prec, char sep) { out.append(num, real_to_chars(v, num, prec)); out.push_back(sep); };
-    for (const auto& q : results[ref_id]) {
-        if (ref_id >= q.id) continue;
-        const IdResult* p = find_id(results[q.id], ref_id);
-        if (!p) continue;                                   // the reference asserts symmetry here
+    void u(uint64_t v) { s.append(num, uint_to_chars(v, num)); }
+    void i(int64_t v) { if (v < 0) { s.push_back('-'); v = -v; } u((uint64_t)v); }
+    void r(double v, int prec) { s.append(num, real_to_chars(v, num, prec)); }
+};
+
+// column writers, indexed by Comp (the enum's order); `m` = 100 with --out-in-percent, else 1
+typedef void (*ColumnFn)(LineOut&, const Direction&, double m);
+inline const ColumnFn* column_table()
+{
+    static const ColumnFn t[15] = {
+        /* query       */ [](LineOut& o, const Direction& d, double) { o.s.append(*d.qname); },
+        /* reference   */ [](LineOut& o, const Direction& d, double) { o.s.append(*d.rname); },
+        /* qidx        */ [](LineOut& o, const Direction& d, double) { o.u(d.qidx); },
+        /* ridx        */ [](LineOut& o, const Direction& d, double) { o.u(d.ridx); },
+        /* qlen        */ [](LineOut& o, const Direction& d, double) { o.u(d.qlen); },
+        /* rlen        */ [](LineOut& o, const Direction& d, double) { o.u(d.rlen); },
+        /* tani        */ [](LineOut& o, const Direction& d, double m) { o.r(m * d.tani, 6); },
+        /* gani        */ [](LineOut& o, const Direction& d, double m) { o.r(m * d.gani, 6); },
+        /* ani         */ [](LineOut& o, const Direction& d, double m) { o.r(m * d.ani, 6); },
+        /* qcov        */ [](LineOut& o, const Direction& d, double m) { o.r(m * d.qcov, 6); },
+        /* rcov        */ [](LineOut& o, const Direction& d, double m) { o.r(m * d.rcov, 6); },
+        /* len_ratio   */ [](LineOut& o, const Direction& d, double) {
+            if (d.qlen && d.rlen) o.r(d.qlen < d.rlen ? (double)d.qlen / d.rlen : (double)d.rlen / d.qlen, 4);
+            else o.s.push_back('0'); },
+        /* nt_match    */ [](LineOut& o, const Direction& d, double) { o.i(d.nt_match); },
+        /* nt_mismatch */ [](LineOut& o, const Direction& d, double) { o.i(d.nt_mismatch); },
+        /* num_alns    */ [](LineOut& o, const Direction& d, double) { o.i(d.num_alns); }};
+    return t;
+}
+
+// --out-filter: minimum values per ratio column (a line is dropped when any ratio is below its minimum)
+struct Cut { double Direction::*field; double min; };
+inline std::vector<Cut> make_cuts(const EmitParams& ep)
+{
+    std::vector<Cut> cuts;
+    if (!ep.filter_mask) return cuts;
+    static const std::pair<Comp, double Direction::*> ratio[] = {
+        {Comp::tani, &Direction::tani}, {Comp::gani, &Direction::gani}, {Comp::ani, &Direction::ani},
+        {Comp::qcov, &Direction::qcov}, {Comp::rcov, &Direction::rcov}};
+    for (auto& x : ratio) cuts.push_back(Cut{x.second, ep.filter_vals[(int)x.first]});
+    return cuts;
+}
+
+inline void write_direction(const Direction& d, const EmitParams& ep, const std::vector<Cut>& cuts, std::string& out)
+{
+    for (const Cut& c : cuts) if (d.*(c.field) < c.min) return;
+    LineOut o{out, {0}};
+    const ColumnFn* col = column_table();
+    const double m = ep.in_percent ? 100 : 1;
+    bool first = true;
+    for (Comp c : ep.comps) {
+        if (!first) out.push_back('\t');
+        first = false;
+        col[(int)c](o, d, m);
+    }
+    out.push_back('\n');
+}
+
+// Text of the unordered pairs {a < b} led by genome a (one reference row of the output file):
+// two TSV lines per pair (b against a, then a against b), or one single-txt line.
+inline void format_row(const std::vector<Genome>& g, const std::vector<uint32_t>& len, const PairTable& T, const EmitParams& ep,
+                       const std::vector<Cut>& cuts, uint32_t a, std::string& out)
+{
+    const uint64_t cnt = T.row_size(a);
+    for (uint64_t j = T.first_above(a); j < cnt; ++j) {
+        const uint32_t b = T.id_at(a, j);
+        const lzani_result& X = T.at(a, j);                 // parse(query = b, ref = a)
+        const lzani_result* Y = T.find(b, a);               // parse(query = a, ref = b)
+        if (!Y) continue;                                   // the reference asserts symmetry here (lz_matcher.cpp:417-418)
         if (ep.single_txt) {
-            put_u(ref_id, ' '); put_u(q.id, ' ');
-            put_i(p->r.sym_in_matches, ' '); put_i(p->r.sym_in_literals, ' '); put_i(p->r.no_components, ' ');
-            put_i(q.r.sym_in_matches, ' '); put_i(q.r.sym_in_literals, ' '); put_i(q.r.no_components, '\n');
+            LineOut o{out, {0}};
+            o.u(a); out.push_back(' '); o.u(b);
+            for (const lzani_result* r : {Y, &X}) {
+                out.push_back(' '); o.i(r->sym_in_matches); out.push_back(' '); o.i(r->sym_in_literals); out.push_back(' '); o.i(r->no_components);
+            }
+            out.push_back('\n');
             continue;
         }
-        const std::string* names[2] = {&g[ref_id].name, &g[q.id].name};
-        const uint32_t ids[2] = {ref_id, q.id};
-        auto seq_len = [&](uint32_t i) { return (uint32_t)g[i].codes.size() - (g[i].no_parts - 1) * (uint32_t)ep.mrd; };
-        const uint32_t len[2] = {seq_len(q.id), seq_len(ref_id)};
-        const int32_t mat[2] = {q.r.sym_in_matches, p->r.sym_in_matches};
-        const int32_t lit[2] = {q.r.sym_in_literals, p->r.sym_in_literals};
-        const int32_t reg[2] = {q.r.no_components, p->r.no_components};
-        const double tani = (double)(mat[0] + mat[1]) / (len[0] + len[1]);
-        const double gani[2] = {(double)mat[0] / len[0], (double)mat[1] / len[1]};
-        const double ani[2] = {mat[0] + lit[0] != 0 ? (double)mat[0] / (mat[0] + lit[0]) : 0,
-                               mat[1] + lit[1] != 0 ? (double)mat[1] / (mat[1] + lit[1]) : 0};
-        const double cov[2] = {(double)(mat[0] + lit[0]) / len[0], (double)(mat[1] + lit[1]) / len[1]};
-        for (int i = 0; i < 2; ++i) {
-            if (ep.filter_mask != 0) {
-                if (gani[i] < ep.filter_vals[(int)Comp::gani]) continue;
-                if (ani[i] < ep.filter_vals[(int)Comp::ani]) continue;
-                if (tani < ep.filter_vals[(int)Comp::tani]) continue;
-                if (cov[i] < ep.filter_vals[(int)Comp::qcov]) continue;
-                if (cov[!i] < ep.filter_vals[(int)Comp::rcov]) continue;
-            }
-            for (Comp oc : ep.comps) {
-                switch (oc) {
-                case Comp::ridx: put_u(ids[i], '\t'); break;
-                case Comp::qidx: put_u(ids[!i], '\t'); break;
-                case Comp::reference: out.append(*names[i]); out.push_back('\t'); break;
-                case Comp::query: out.append(*names[!i]); out.push_back('\t'); break;
-                case Comp::qcov: put_r(mult * cov[i], 6, '\t'); break;
-                case Comp::rcov: put_r(mult * cov[!i], 6, '\t'); break;
-                case Comp::gani: put_r(mult * gani[i], 6, '\t'); break;
-                case Comp::rlen: put_u(len[!i], '\t'); break;
-                case Comp::qlen: put_u(len[i], '\t'); break;
-                case Comp::len_ratio:
-                    if (len[0] && len[1]) {
-                        double lr = len[i] < len[!i] ? (double)len[i] / len[!i] : (double)len[!i] / len[i];
-                        put_r(lr, 4, '\t');
-                    } else { out.push_back('0'); out.push_back('\t'); }
-                    break;
-                case Comp::ani: put_r(mult * ani[i], 6, '\t'); break;
-                case Comp::num_alns: put_i(reg[i], '\t'); break;
-                case Comp::nt_mismatch: put_i(lit[i], '\t'); break;
-                case Comp::nt_match: put_i(mat[i], '\t'); break;
-                case Comp::tani: put_r(mult * tani, 6, '\t'); break;
-                }
-            }
-            if (!ep.comps.empty()) out.pop_back();
-            out.push_back('\n');
-        }
+        const double tani = (double)(X.sym_in_matches + Y->sym_in_matches) / (len[b] + len[a]);
+        write_direction(make_direction(g, len, b, a, X, *Y, tani), ep, cuts, out);
+        write_direction(make_direction(g, len, a, b, *Y, X, tani), ep, cuts, out);
     }
 }
 
-inline bool store_results(const std::vector<Genome>& g, const ResultRows& results, const EmitParams& ep)
+inline bool store_results(const std::vector<Genome>& g, const PairTable& T, const EmitParams& ep)
 {
     std::string fn_ids, fn_anis;
     if (!ep.single_txt) {
@@ -211,15 +296,17 @@ inline bool store_results(const std::vector<Genome>& g, const ResultRows& result
 
     std::ofstream ofs(fn_ids, std::ios::binary);
     if (!ofs.is_open()) { std::cerr << "Cannot open output file: " << fn_ids << std::endl; return false; }
-    auto seq_len = [&](size_t i) { return (uint32_t)g[i].codes.size() - (g[i].no_parts - 1) * (uint32_t)ep.mrd; };
+    // reported length: separators between the contigs of a multi-part item are not counted (lz_matcher.cpp:430-431)
+    std::vector<uint32_t> len(g.size());
+    for (size_t i = 0; i < g.size(); ++i) len[i] = (uint32_t)g[i].codes.size() - (g[i].no_parts - 1) * (uint32_t)ep.mrd;
     if (ep.single_txt) {
         ofs << ep.params_dump;
         ofs << "[no_input_sequences]\n" << g.size() << "\n[input_sequences]\n";
-        for (size_t i = 0; i < g.size(); ++i) ofs << g[i].name << " " << seq_len(i) << " " << g[i].no_parts << "\n";
+        for (size_t i = 0; i < g.size(); ++i) ofs << g[i].name << " " << len[i] << " " << g[i].no_parts << "\n";
         ofs << "[lz_similarities]\n";
     } else {
         ofs << "id\tseq_len\tno_parts\n";
-        for (size_t i = 0; i < g.size(); ++i) ofs << g[i].name << "\t" << seq_len(i) << "\t" << g[i].no_parts << "\n";
+        for (size_t i = 0; i < g.size(); ++i) ofs << g[i].name << "\t" << len[i] << "\t" << g[i].no_parts << "\n";
         ofs.close();
         ofs.open(fn_anis, std::ios::binary);
         if (!ofs.is_open()) { std::cerr << "Cannot open output file: " << fn_anis << std::endl; return false; }
@@ -233,7 +320,8 @@ inline bool store_results(const std::vector<Genome>& g, const ResultRows& result
     }
 
     // formatter threads fill per-row strings in blocks; the main thread writes them in row order
-    const size_t n = results.size();
+    const std::vector<Cut> cuts = make_cuts(ep);
+    const size_t n = T.n;
     const size_t block = 256;
     std::vector<std::string> text(std::min(n, block * 64));
     for (size_t base = 0; base < n; base += text.size()) {
@@ -244,7 +332,7 @@ inline bool store_results(const std::vector<Genome>& g, const ResultRows& result
                 size_t k = next.fetch_add(1);
                 if (k >= cnt) break;
                 text[k].clear();
-                format_row(g, results, ep, (uint32_t)(base + k), text[k]);
+                format_row(g, len, T, ep, cuts, (uint32_t)(base + k), text[k]);
             }
         };
         std::vector<std::thread> th;

@@ -170,6 +170,19 @@ static bool parse_params(int argc, char** argv)
         else { cerr << "Unknown parameter: " << argv[i] << endl; usage(); exit(1); }
     }
     if (P.inputs.empty()) { cerr << "Input file names not provided\n"; return false; }
+    // The engine's parameter envelope (lz-ani_amd/csrc/lzani_layout.h: params_supported).  The reference accepts any
+    // ints here (lz-ani.cpp:205-260); values outside the envelope are refused before any file is read.
+    struct { const char* flag; int v, lo, hi; } env[] = {
+        {"--msl", z.min_seed_len, 1, 32}, {"--mal", z.min_anchor_len, 1, 32}, {"--mrd", z.max_dist_in_ref, 0, 1 << 20},
+        {"--mqd", z.max_dist_in_query, 0, 64}, {"--aw", z.approx_window, 1, 64}, {"--ar", z.approx_run_len, -(1 << 30), 64},
+        {"--am", z.approx_mismatches, 0, 1 << 30}};
+    for (auto& e : env)
+        if (e.v < e.lo || e.v > e.hi) {
+            cerr << "Unsupported value: " << e.flag << " " << e.v << " (this engine supports " << e.lo << " .. " << e.hi << ")" << endl;
+            exit(1);
+        }
+    if (P.verbosity >= 2 && (z.min_anchor_len > 15 || z.min_seed_len > 15))
+        cerr << "Note: --mal / --msl above 15: the engine runs without per-genome k-mer words (generic path, several times slower)" << endl;
     return true;
 }
 
@@ -208,10 +221,17 @@ struct Engine {
     void (*destroy)(lzani_ctx*) = nullptr;
     const char* (*last_error)(const lzani_ctx*) = nullptr;
     int (*set_genomes)(lzani_ctx*, uint32_t, const uint8_t* const*, const uint32_t*) = nullptr;
-    int (*run_rows)(lzani_ctx*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, lzani_result*) = nullptr;
     int (*get_timing)(const lzani_ctx*, lzani_timing*) = nullptr;
     int (*run_rows_regions)(lzani_ctx*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, lzani_result*, lzani_region*,
                             uint64_t, uint64_t*) = nullptr;
+    int (*row_costs)(uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, uint32_t, const uint32_t*, uint64_t*) = nullptr;
+    int (*partition_rows)(uint32_t, const uint64_t*, uint32_t, uint32_t*) = nullptr;
+    int (*group_create)(const lzani_params*, uint32_t, const int*, lzani_group**) = nullptr;
+    void (*group_destroy)(lzani_group*) = nullptr;
+    const char* (*group_last_error)(const lzani_group*) = nullptr;
+    int (*group_set_genomes)(lzani_group*, uint32_t, const uint8_t* const*, const uint32_t*) = nullptr;
+    int (*group_run_rows)(lzani_group*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, lzani_result*) = nullptr;
+    int (*group_get_timing)(const lzani_group*, uint32_t, lzani_timing*, double*) = nullptr;
     bool load(const char* argv0)
     {
         vector<string> cand;
@@ -223,16 +243,15 @@ struct Engine {
         cand.push_back("liblzani_hip.so");
         for (auto& c : cand) if ((so = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
         if (!so) { cerr << "Cannot load liblzani_hip.so (the HIP engine; there is no CPU fallback): " << dlerror() << endl; return false; }
-#define BIND(f, n) f = reinterpret_cast<decltype(f)>(dlsym(so, n)); if (!f) { cerr << "Missing symbol " << n << endl; return false; }
-        BIND(create, "lzani_create") BIND(destroy, "lzani_destroy") BIND(last_error, "lzani_last_error")
-        BIND(set_genomes, "lzani_set_genomes") BIND(run_rows, "lzani_run_rows") BIND(get_timing, "lzani_get_timing")
-        BIND(run_rows_regions, "lzani_run_rows_regions")
+#define BIND(f) f = reinterpret_cast<decltype(f)>(dlsym(so, "lzani_" #f)); if (!f) { cerr << "Missing symbol lzani_" #f << endl; return false; }
+        BIND(create) BIND(destroy) BIND(last_error) BIND(set_genomes) BIND(get_timing) BIND(run_rows_regions)
+        BIND(row_costs) BIND(partition_rows)
+        BIND(group_create) BIND(group_destroy) BIND(group_last_error) BIND(group_set_genomes) BIND(group_run_rows) BIND(group_get_timing)
 #undef BIND
         return true;
     }
 };
 
-// do_matching (lz_matcher.cpp:172-277): rows -> engine(s) -> results[ref] sorted by id
 struct AlnRegion { uint32_t ref, qry; lzani_region r; };
 
 // store_alignment (lz_matcher.cpp:102-169): one BLAST-tab-like row per region; rows of one pair in
@@ -281,65 +300,88 @@ static bool store_alignment(const vector<Genome>& g, vector<AlnRegion>& regs)
     return true;
 }
 
-static bool do_matching(const Engine& E, const vector<Genome>& g, const Filter& flt, ResultRows& results, vector<AlnRegion>* aln)
+// do_matching (lz_matcher.cpp:172-277).  The reference's workers pull reference rows off an atomic counter and
+// run one CParser each; here the whole row table goes to the engine in one call: lzani_group_run_rows deals
+// the rows over the GPUs of the group (cyclic for dense rows, LPT for filtered ones), runs them, gathers the
+// shards over RCCL on the first GPU and copies the results out once, CSR-aligned with T.
+static bool do_matching(const Engine& E, const vector<Genome>& g, Filter& flt, PairTable& T, vector<AlnRegion>* aln)
 {
     const uint32_t n = (uint32_t)g.size();
     if (P.verbosity >= 1) cerr << "All2all sparse" << endl;
-    results.assign(n, {});
+    if (flt.empty()) T.init_dense(n);
+    else { T.init_sparse(flt.rows); vector<vector<uint32_t>>().swap(flt.rows); }   // the reference clears filter rows as it goes (266-267)
     vector<const uint8_t*> ptr(n);
-    vector<uint32_t> len(n);
-    for (uint32_t i = 0; i < n; ++i) { ptr[i] = g[i].codes.data(); len[i] = (uint32_t)g[i].codes.size(); }
-    const int ng = max(1, min<int>(P.gpus, (int)n));
+    vector<uint32_t> len(n), ref_ids(n);
+    for (uint32_t i = 0; i < n; ++i) { ptr[i] = g[i].codes.data(); len[i] = (uint32_t)g[i].codes.size(); ref_ids[i] = i; }
+    const uint32_t* qids = T.dense ? nullptr : T.query_ids.data();
+    const int ng = max(1, min<int>(P.gpus, (int)max<uint32_t>(n, 1)));
+
+    if (!aln) {
+        vector<int> devs(ng);
+        for (int d = 0; d < ng; ++d) devs[d] = P.device + d;
+        lzani_group* grp = nullptr;
+        int rc = E.group_create(&P.lz, (uint32_t)ng, devs.data(), &grp);
+        if (rc != LZANI_OK) {
+            cerr << "LZ matching failed: lzani_group_create failed with code " << rc
+                 << (rc == LZANI_ERR_PARAMS ? " (LZ parameters outside the supported envelope)" : rc == LZANI_ERR_DEVICE ? " (no such GPU, or RCCL could not connect the GPUs)" : "") << endl;
+            return false;
+        }
+        rc = E.group_set_genomes(grp, n, ptr.data(), len.data());
+        if (rc == LZANI_OK) rc = E.group_run_rows(grp, n, ref_ids.data(), T.row_off.data(), qids, T.res.data());
+        if (rc != LZANI_OK) { cerr << "LZ matching failed: " << E.group_last_error(grp) << endl; E.group_destroy(grp); return false; }
+        if (P.verbosity >= 2)
+            for (int d = 0; d < ng; ++d) {
+                lzani_timing t; double gather = 0;
+                if (E.group_get_timing(grp, (uint32_t)d, &t, &gather) == LZANI_OK)
+                    cerr << "GPU " << devs[d] << ": " << t.pairs << " pairs, index " << t.index_ms << " ms, pair kernel " << t.pairs_ms << " ms"
+                         << (d == 0 && ng > 1 ? ", RCCL gather " + to_string(gather) + " ms" : string()) << "\n";
+            }
+        E.group_destroy(grp);
+        return true;
+    }
+
+    // --out-alignment: the per-pair region lists are variable-length, so every GPU's shard comes back through host
+    // memory (lzani_run_rows_regions per context); the rows are dealt by the same partition as above.
+    vector<uint32_t> part(n);
+    {
+        vector<uint64_t> cost;
+        if (!T.dense) { cost.resize(n); E.row_costs(n, ref_ids.data(), T.row_off.data(), qids, n, len.data(), cost.data()); }
+        E.partition_rows(n, T.dense ? nullptr : cost.data(), (uint32_t)ng, part.data());
+    }
     vector<string> errs(ng);
+    mutex mtx;
     auto shard = [&](int d) {
         lzani_ctx* ctx = nullptr;
         int rc = E.create(&P.lz, P.device + d, &ctx);
         if (rc != LZANI_OK) { errs[d] = "lzani_create failed with code " + to_string(rc) + (rc == LZANI_ERR_PARAMS ? " (LZ parameters outside the supported envelope)" : ""); return; }
         rc = E.set_genomes(ctx, n, ptr.data(), len.data());
-        vector<uint32_t> ref_ids, query_ids;
+        vector<uint32_t> rows, query_ids;
         vector<uint64_t> row_off(1, 0);
-        for (uint32_t r = (uint32_t)d; r < n; r += (uint32_t)ng) {
-            ref_ids.push_back(r);
-            if (flt.empty()) row_off.push_back(row_off.back() + (n - 1));
-            else { for (auto q : flt.rows[r]) query_ids.push_back(q); row_off.push_back(query_ids.size()); }
+        for (uint32_t r = 0; r < n; ++r) {
+            if (part[r] != (uint32_t)d) continue;
+            rows.push_back(r);
+            if (!T.dense) query_ids.insert(query_ids.end(), T.query_ids.begin() + (ptrdiff_t)T.row_off[r], T.query_ids.begin() + (ptrdiff_t)T.row_off[r + 1]);
+            row_off.push_back(row_off.back() + T.row_size(r));
         }
         vector<lzani_result> out(row_off.back());
         vector<lzani_region> regs;
-        if (rc == LZANI_OK && !aln)
-            rc = E.run_rows(ctx, (uint32_t)ref_ids.size(), ref_ids.data(), row_off.data(), flt.empty() ? nullptr : query_ids.data(), out.data());
-        else if (rc == LZANI_OK) {
-            uint64_t cap = max<uint64_t>(1024, row_off.back() / 4), cnt = 0;
-            for (;;) {
-                regs.resize(cap);
-                rc = E.run_rows_regions(ctx, (uint32_t)ref_ids.size(), ref_ids.data(), row_off.data(), flt.empty() ? nullptr : query_ids.data(),
-                                        out.data(), regs.data(), cap, &cnt);
-                if (rc != LZANI_OK || cnt <= cap) break;
-                cap = cnt;
-            }
-            regs.resize(rc == LZANI_OK ? cnt : 0);
+        uint64_t cap = max<uint64_t>(1024, row_off.back() / 4), cnt = 0;
+        while (rc == LZANI_OK) {
+            regs.resize(cap);
+            rc = E.run_rows_regions(ctx, (uint32_t)rows.size(), rows.data(), row_off.data(), T.dense ? nullptr : query_ids.data(),
+                                    out.data(), regs.data(), cap, &cnt);
+            if (rc != LZANI_OK || cnt <= cap) break;
+            cap = cnt;
         }
         if (rc != LZANI_OK) errs[d] = E.last_error(ctx);
         else {
-            for (size_t k = 0; k < ref_ids.size(); ++k) {
-                uint32_t r = ref_ids[k];
-                auto& row = results[r];
-                row.reserve(row_off[k + 1] - row_off[k]);
-                for (uint64_t e = row_off[k]; e < row_off[k + 1]; ++e) {
-                    uint32_t j = (uint32_t)(e - row_off[k]);
-                    uint32_t q = flt.empty() ? j + (j >= r ? 1u : 0u) : query_ids[e];
-                    row.push_back(IdResult{q, out[e]});
-                }
-                sort(row.begin(), row.end(), [](const IdResult& a, const IdResult& b) { return a.id < b.id; });
-            }
-            if (aln) {
-                static mutex mtx;
-                lock_guard<mutex> lck(mtx);
-                for (const auto& x : regs) {
-                    size_t k = upper_bound(row_off.begin(), row_off.end(), x.pair) - row_off.begin() - 1;
-                    uint32_t r = ref_ids[k], j = (uint32_t)(x.pair - row_off[k]);
-                    uint32_t q = flt.empty() ? j + (j >= r ? 1u : 0u) : query_ids[x.pair];
-                    aln->push_back(AlnRegion{r, q, x});
-                }
+            regs.resize(cnt);
+            for (size_t k = 0; k < rows.size(); ++k)
+                copy(out.begin() + (ptrdiff_t)row_off[k], out.begin() + (ptrdiff_t)row_off[k + 1], T.res.begin() + (ptrdiff_t)T.row_off[rows[k]]);
+            lock_guard<mutex> lck(mtx);
+            for (const auto& x : regs) {
+                size_t k = upper_bound(row_off.begin(), row_off.end(), x.pair) - row_off.begin() - 1;
+                aln->push_back(AlnRegion{rows[k], T.id_at(rows[k], x.pair - row_off[k]), x});
             }
             if (P.verbosity >= 2) {
                 lzani_timing t;
@@ -357,22 +399,33 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, const Filter& 
     return true;
 }
 
-static bool write_raw(const string& fn, const ResultRows& res)
+// test seams: the matching stage's integers as text, "ref query mat lit comp" per directed pair
+static bool write_raw(const string& fn, const PairTable& T)
 {
     ofstream o(fn);
     if (!o.is_open()) return false;
-    for (size_t r = 0; r < res.size(); ++r)
-        for (auto& x : res[r]) o << r << ' ' << x.id << ' ' << x.r.sym_in_matches << ' ' << x.r.sym_in_literals << ' ' << x.r.no_components << '\n';
+    for (uint32_t r = 0; r < T.n; ++r)
+        for (uint64_t j = 0; j < T.row_size(r); ++j) {
+            const lzani_result& x = T.at(r, j);
+            o << r << ' ' << T.id_at(r, j) << ' ' << x.sym_in_matches << ' ' << x.sym_in_literals << ' ' << x.no_components << '\n';
+        }
     return true;
 }
-static bool read_raw(const string& fn, size_t n, ResultRows& res)
+static bool read_raw(const string& fn, size_t n, PairTable& T)
 {
     ifstream in(fn);
     if (!in.is_open()) { cerr << "Cannot open file: " << fn << endl; return false; }
-    res.assign(n, {});
-    size_t r; IdResult x;
-    while (in >> r >> x.id >> x.r.sym_in_matches >> x.r.sym_in_literals >> x.r.no_components) { if (r >= n || x.id >= n) return false; res[r].push_back(x); }
-    for (auto& row : res) sort(row.begin(), row.end(), [](const IdResult& a, const IdResult& b) { return a.id < b.id; });
+    struct Rec { uint32_t q; lzani_result r; };
+    vector<vector<Rec>> rows(n);
+    size_t r; Rec x;
+    while (in >> r >> x.q >> x.r.sym_in_matches >> x.r.sym_in_literals >> x.r.no_components) { if (r >= n || x.q >= n) return false; rows[r].push_back(x); }
+    vector<vector<uint32_t>> ids(n);
+    for (size_t k = 0; k < n; ++k) {
+        stable_sort(rows[k].begin(), rows[k].end(), [](const Rec& a, const Rec& b) { return a.q < b.q; });
+        for (auto& e : rows[k]) ids[k].push_back(e.q);
+    }
+    T.init_sparse(ids);
+    for (size_t k = 0; k < n; ++k) for (size_t j = 0; j < rows[k].size(); ++j) T.res[T.row_off[k] + j] = rows[k][j].r;
     return true;
 }
 
@@ -413,7 +466,7 @@ static bool run_all2all(const char* argv0)
     if (!flt.empty()) { if (P.verbosity >= 1) cerr << "Reordering filter" << endl; reorder_filter(flt, map); }
     stamp("Reordering sequences");
 
-    ResultRows results;
+    PairTable results;
     if (!P.results_in.empty()) { if (!read_raw(P.results_in, g.size(), results)) return false; }
     else {
         Engine E;

@@ -27,7 +27,10 @@ ERRORS = {-1: "LZANI_ERR_ARG", -2: "LZANI_ERR_PARAMS", -3: "LZANI_ERR_DEVICE",
 
 EXPORTS = ("lzani_default_params", "lzani_create", "lzani_destroy", "lzani_last_error",
            "lzani_set_genomes", "lzani_run_rows", "lzani_run_rows_device", "lzani_get_timing",
-           "lzani_debug_get_index", "lzani_run_rows_regions")
+           "lzani_debug_get_index", "lzani_run_rows_regions", "lzani_get_layout",
+           "lzani_row_costs", "lzani_partition_rows", "lzani_comm_unique_id", "lzani_comm_init", "lzani_comm_allgather",
+           "lzani_comm_gatherv", "lzani_group_create", "lzani_group_destroy", "lzani_group_last_error",
+           "lzani_group_set_genomes", "lzani_group_run_rows", "lzani_group_get_timing")
 
 
 class LzaniError(RuntimeError):
@@ -39,14 +42,21 @@ class Timing(C.Structure):
                 ("index_launches", C.c_uint32), ("pairs", C.c_uint64)]
 
 
+class LayoutInfo(C.Structure):
+    _fields_ = [("key_bits", C.c_int32), ("dir_bits", C.c_int32), ("pos_bits", C.c_int32), ("tag_mask", C.c_uint32),
+                ("kmer_words", C.c_int32), ("bucket_table", C.c_int32), ("tag_words", C.c_int32), ("n_free", C.c_int32),
+                ("slots", C.c_uint32), ("batches_last_run", C.c_uint32), ("bytes_per_slot", C.c_uint64),
+                ("bytes_genomes", C.c_uint64)]
+
+
 def build_library(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     deps = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("lzani_core.h", "lzani_layout.h", "lzani_kernels_index.h",
-                                                             "lzani_kernels_pairs.h")] + [os.path.join(ROOT, "include", "lzani.h")]
+                                                             "lzani_kernels_pairs.h", "lzani_multi.h")] + [os.path.join(ROOT, "include", "lzani.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wno-unused-value", "-o", LIB_PATH, SRC]
+           "-Wno-unused-value", "-o", LIB_PATH, SRC, "-lrccl"]
     subprocess.check_call(cmd)
     return LIB_PATH
 
@@ -70,9 +80,24 @@ def load_library():
         lib.lzani_run_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.lzani_run_rows_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.lzani_get_timing.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lzani_get_layout.argtypes = [C.c_void_p, C.c_void_p]
         lib.lzani_run_rows_regions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lzani_debug_get_index.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        lib.lzani_row_costs.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.lzani_partition_rows.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.lzani_comm_unique_id.argtypes = [C.c_void_p]
+        lib.lzani_comm_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.lzani_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        lib.lzani_comm_gatherv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        lib.lzani_group_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.lzani_group_destroy.argtypes = [C.c_void_p]
+        lib.lzani_group_destroy.restype = None
+        lib.lzani_group_last_error.argtypes = [C.c_void_p]
+        lib.lzani_group_last_error.restype = C.c_char_p
+        lib.lzani_group_set_genomes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.lzani_group_run_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.lzani_group_get_timing.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -93,6 +118,88 @@ def dense_rows(n, rows=None):
     ref_ids = np.arange(n, dtype=np.uint32) if rows is None else np.asarray(rows, dtype=np.uint32)
     row_off = np.arange(len(ref_ids) + 1, dtype=np.uint64) * np.uint64(max(n - 1, 0))
     return ref_ids, row_off
+
+
+def row_costs(ref_ids, row_off, query_ids, lens):
+    """cost(row) = sum of query lengths + LZANI_ROW_COST_REF_WEIGHT * reference length (lzani_row_costs; no GPU needed)."""
+    lib = load_library()
+    ref_ids = np.ascontiguousarray(ref_ids, dtype=np.uint32)
+    row_off = np.ascontiguousarray(row_off, dtype=np.uint64)
+    q = None if query_ids is None else np.ascontiguousarray(query_ids, dtype=np.uint32)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    cost = np.zeros(len(ref_ids), dtype=np.uint64)
+    rc = lib.lzani_row_costs(len(ref_ids), _ptr(ref_ids), _ptr(row_off), _ptr(q), len(lens), _ptr(lens), _ptr(cost))
+    if rc != 0:
+        raise LzaniError(f"lzani_row_costs: {ERRORS.get(rc, rc)}")
+    return cost
+
+
+def partition_rows(n_rows, n_parts, row_cost=None):
+    """Shard index of every row (lzani_partition_rows: cyclic without costs, greedy LPT with; no GPU needed)."""
+    lib = load_library()
+    cost = None if row_cost is None else np.ascontiguousarray(row_cost, dtype=np.uint64)
+    part = np.zeros(n_rows, dtype=np.uint32)
+    rc = lib.lzani_partition_rows(n_rows, _ptr(cost), n_parts, _ptr(part))
+    if rc != 0:
+        raise LzaniError(f"lzani_partition_rows: {ERRORS.get(rc, rc)}")
+    return part
+
+
+def comm_unique_id():
+    lib = load_library()
+    buf = (C.c_uint8 * 128)()
+    rc = lib.lzani_comm_unique_id(buf)
+    if rc != 0:
+        raise LzaniError(f"lzani_comm_unique_id: {ERRORS.get(rc, rc)}")
+    return bytes(buf)
+
+
+class Group:
+    """lzani_group_*: one process, several GPUs (what `lz-ani --gpus n` uses)."""
+
+    def __init__(self, params=None, devices=(0,)):
+        self.lib = load_library()
+        arr, self.params = params_array(params)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self.lib.lzani_group_create(arr, len(devices), devs, C.byref(h))
+        if rc != 0:
+            raise LzaniError(f"lzani_group_create failed: {ERRORS.get(rc, rc)}")
+        self.h = h
+        self.n_dev = len(devices)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lzani_group_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.lzani_group_last_error(self.h)
+            raise LzaniError(f"{what}: {ERRORS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def set_genomes(self, seqs):
+        seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in seqs]
+        ptrs = (C.c_void_p * len(seqs))(*[s.ctypes.data for s in seqs])
+        lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+        self._check(self.lib.lzani_group_set_genomes(self.h, len(seqs), ptrs, _ptr(lens)), "lzani_group_set_genomes")
+        self.n = len(seqs)
+
+    def run_rows(self, ref_ids, row_off, query_ids=None):
+        ref_ids = np.ascontiguousarray(ref_ids, dtype=np.uint32)
+        row_off = np.ascontiguousarray(row_off, dtype=np.uint64)
+        q = None if query_ids is None else np.ascontiguousarray(query_ids, dtype=np.uint32)
+        n_pairs = int(row_off[-1]) if len(row_off) else 0
+        out = np.zeros((n_pairs, 3), dtype=np.int32)
+        self._check(self.lib.lzani_group_run_rows(self.h, len(ref_ids), _ptr(ref_ids), _ptr(row_off), _ptr(q), _ptr(out)),
+                    "lzani_group_run_rows")
+        return out
+
+    def timing(self, device_index=0):
+        t = Timing()
+        g = C.c_double(0)
+        self._check(self.lib.lzani_group_get_timing(self.h, device_index, C.byref(t), C.byref(g)), "lzani_group_get_timing")
+        return dict(index_ms=t.index_ms, pairs_ms=t.pairs_ms, pair_launches=t.pair_launches, pairs=t.pairs, gather_ms=g.value)
 
 
 class Engine:
@@ -180,11 +287,30 @@ class Engine:
         out[~np.eye(n, dtype=bool)] = flat
         return out
 
+    def comm_init(self, n_ranks, rank, unique_id):
+        """RCCL communicator of this context (one process per GPU); unique_id = comm_unique_id() of rank 0."""
+        buf = (C.c_uint8 * 128)(*unique_id)
+        self._check(self.lib.lzani_comm_init(self.h, n_ranks, rank, buf), "lzani_comm_init")
+
+    def comm_allgather(self, d_send_ptr, d_recv_ptr, n_results):
+        self._check(self.lib.lzani_comm_allgather(self.h, C.c_void_p(int(d_send_ptr)), C.c_void_p(int(d_recv_ptr)), n_results),
+                    "lzani_comm_allgather")
+
+    def comm_gatherv(self, d_send_ptr, d_recv_ptr, counts, root=0):
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        self._check(self.lib.lzani_comm_gatherv(self.h, C.c_void_p(int(d_send_ptr)), C.c_void_p(int(d_recv_ptr or 0)),
+                                                _ptr(counts), root), "lzani_comm_gatherv")
+
     def timing(self):
         t = Timing()
         self._check(self.lib.lzani_get_timing(self.h, C.byref(t)), "lzani_get_timing")
         return dict(index_ms=t.index_ms, pairs_ms=t.pairs_ms, pair_launches=t.pair_launches,
                     index_launches=t.index_launches, pairs=t.pairs)
+
+    def layout(self):
+        o = LayoutInfo()
+        self._check(self.lib.lzani_get_layout(self.h, C.byref(o)), "lzani_get_layout")
+        return {k: getattr(o, k) for k, _ in LayoutInfo._fields_}
 
     def debug_index(self, gid):
         mrd = self.params["mrd"]

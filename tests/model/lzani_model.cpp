@@ -12,6 +12,7 @@
 
 #include "../../lz-ani_amd/csrc/lzani_core.h"
 #include "../../lz-ani_amd/csrc/lzani_layout.h"
+#include "lane_wave.h"
 
 using namespace lzani;
 

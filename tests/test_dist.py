@@ -1,8 +1,8 @@
-"""CPU, world_size 2 over gloo: the N > 1 host logic -- cyclic row shards, padded all_gather,
+"""CPU, world_size 2 over gloo: the N > 1 host logic -- the C-ABI's row partition (lzani_partition_rows /
+lzani_row_costs: the same code lzani_group_run_rows and bench.py use), padded all-gather, ragged gather,
 reassembly -- with the oracle standing in for the per-rank compute (there is no GPU here)."""
 import os
 import socket
-import sys
 
 import numpy as np
 import pytest
@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import lzani_ctypes as L
 import oracle as O
 import shard as SH
 import synth_genomes as SG
@@ -31,7 +32,6 @@ def _worker(rank, world, port, n, out_path):
     shard = np.zeros(SH.shard_len(n, world), dtype=np.int32)
     buf = shard.reshape(SH.shard_rows_max(n, world), n - 1, 3)
     for i, r in enumerate(rows):                 # this rank's rows only
-        ref_ids = np.array([r], dtype=np.uint32)
         for j, q in enumerate([q for q in range(n) if q != r]):
             buf[i, j] = O.oracle_pair(seqs[r], seqs[q])
     t = torch.from_numpy(shard)
@@ -59,3 +59,119 @@ def test_shard_partition_properties():
             rows = np.concatenate([SH.row_shard(n, r, world) for r in range(world)])
             assert sorted(rows.tolist()) == list(range(n))
             assert max(len(SH.row_shard(n, r, world)) for r in range(world)) == SH.shard_rows_max(n, world)
+            assert SH.row_shard(n, 0, world).tolist() == list(range(0, n, world))        # cyclic
+    # slabs of a pass cover every row once and wrap around
+    n, slab = 1030, 500
+    seen = np.concatenate([SH.slab_rows(n, s, slab) for s in range(3)])
+    assert sorted(seen.tolist()) == list(range(n))
+    assert np.array_equal(SH.slab_rows(n, 3, slab), SH.slab_rows(n, 0, slab))
+
+
+def heavy_tailed_csr(n_target, seed):
+    """A symmetric sparse pair list as a kmer-db prefilter leaves it: families of heavy-tailed size (40 % singletons,
+    40 % 2-10, 15 % 11-100, 5 % 101-400), all same-family pairs plus one random cross pair per genome."""
+    st = SG.Stream(seed)
+    fam_of = []
+    while len(fam_of) < n_target:
+        u = st.one()
+        sz = 1 if u < 0.4 else st.randint(2, 10) if u < 0.8 else st.randint(11, 100) if u < 0.95 else st.randint(101, 400)
+        fam_of += [len(set(fam_of))] * min(sz, n_target - len(fam_of))
+    fam_of = np.array(fam_of)
+    n = len(fam_of)
+    rows = [[] for _ in range(n)]
+    start = 0
+    for f in range(fam_of.max() + 1):
+        m = int((fam_of == f).sum())
+        for a in range(start, start + m):
+            rows[a] += [b for b in range(start, start + m) if b != a]
+        start += m
+    for a in range(n):
+        b = st.randint(0, n - 1)
+        if b != a and b not in rows[a]:
+            rows[a].append(b)
+            rows[b].append(a)
+    lens = np.array([st.randint(30000, 50000) for _ in range(n)], dtype=np.uint32)
+    ref_ids = np.arange(n, dtype=np.uint32)
+    row_off = np.zeros(n + 1, dtype=np.uint64)
+    row_off[1:] = np.cumsum([len(r) for r in rows])
+    q = np.array([x for r in rows for x in r], dtype=np.uint32)
+    return ref_ids, row_off, q, lens
+
+
+def test_lpt_partition_balances_heavy_tailed_rows():
+    """BASELINE configs[4] shape: the cost of a filtered row spans three orders of magnitude; greedy LPT on
+    cost(row) = sum(Lq) + c*Lr keeps the heaviest shard within 10 % of the mean at 2, 4 and 8 GPUs, while
+    dealing the same rows cyclically does not."""
+    ref_ids, row_off, q, lens = heavy_tailed_csr(6000, 21)
+    cost = L.row_costs(ref_ids, row_off, q, lens)
+    # the cost is what the header says it is
+    k = 4321
+    assert int(cost[k]) == int(lens[q[int(row_off[k]):int(row_off[k + 1])]].astype(np.int64).sum()) + 6 * int(lens[k])
+    sizes = np.diff(row_off.astype(np.int64))
+    assert sizes.max() > 100 * max(1, sizes.min()) and (sizes <= 3).mean() > 0.01    # really heavy-tailed
+    for world in (2, 4, 8):
+        part = L.partition_rows(len(ref_ids), world, cost)
+        assert part.min() == 0 and part.max() == world - 1
+        load = np.bincount(part, weights=cost.astype(np.float64), minlength=world)
+        assert load.max() / load.mean() <= 1.1, (world, load.max() / load.mean())
+        # the algorithm is the stated one: heaviest row first onto the least loaded shard (ties: lowest shard)
+        want = np.zeros(len(cost), dtype=np.uint32)
+        acc = [0] * world
+        for r in np.argsort(-cost.astype(np.int64), kind="stable"):
+            p = min(range(world), key=lambda x: (acc[x], x))
+            want[r] = p
+            acc[p] += int(cost[r])
+        assert np.array_equal(part, want)
+    cyc = L.partition_rows(len(ref_ids), 8, None)
+    assert np.array_equal(cyc, np.arange(len(ref_ids)) % 8)
+    with pytest.raises(L.LzaniError):
+        L.partition_rows(3, 0, None)
+
+
+def _worker_csr(rank, world, port, out_path):
+    """Filtered rows: every rank takes its LPT shard, computes it (oracle), and the ragged shards are gathered
+    to rank 0 in rank order -- the data movement of lzani_comm_gatherv / lzani_group_run_rows -- and put back
+    into the caller's CSR order."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, seqs = SG.make_set(40, 23, lmin=1200, lmax=2500, fam=8)
+    ref_ids, row_off, q, _ = heavy_tailed_csr(40, 5)
+    lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+    part = L.partition_rows(len(ref_ids), world, L.row_costs(ref_ids, row_off, q, lens))
+    counts = [int(np.diff(row_off.astype(np.int64))[part == p].sum()) for p in range(world)]
+    mine = np.nonzero(part == rank)[0]
+    shard = np.zeros((max(counts), 3), dtype=np.int32)                        # padded to the largest shard for gloo
+    at = 0
+    for k in mine:
+        for e in range(int(row_off[k]), int(row_off[k + 1])):
+            shard[at] = O.oracle_pair(seqs[ref_ids[k]], seqs[q[e]])
+            at += 1
+    assert at == counts[rank]
+    bufs = [torch.zeros(shard.shape, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(bufs, torch.from_numpy(shard))
+    if rank == 0:
+        out = np.zeros((len(q), 3), dtype=np.int32)
+        for p in range(world):
+            got, at = bufs[p].numpy(), 0
+            for k in np.nonzero(part == p)[0]:
+                cnt = int(row_off[k + 1] - row_off[k])
+                out[int(row_off[k]):int(row_off[k + 1])] = got[at:at + cnt]
+                at += cnt
+        np.save(out_path, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_filtered_rows_lpt_gather_world2(tmp_path):
+    out = str(tmp_path / "csr.npy")
+    mp.spawn(_worker_csr, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    _, seqs = SG.make_set(40, 23, lmin=1200, lmax=2500, fam=8)
+    ref_ids, row_off, q, _ = heavy_tailed_csr(40, 5)
+    full = O.oracle_all2all(seqs, None, threads=4)
+    e = 0
+    for k, r in enumerate(ref_ids):
+        for x in q[int(row_off[k]):int(row_off[k + 1])]:
+            assert tuple(got[e]) == tuple(full[r, x]), (k, r, x)
+            e += 1
+    assert e == len(q)

@@ -384,13 +384,208 @@ def test_index_build_mid_size_directories():
         assert np.array_equal(got, O.oracle_all2all(seqs, None, threads=16))
 
 
-def test_thread_per_pair_variant(monkeypatch):
-    """The opt-in thread-per-pair kernel (LZANI_KERNEL=tpp; slower, kept for experiments) is bit-exact too."""
-    monkeypatch.setenv("LZANI_KERNEL", "tpp")
-    _, seqs = SG.make_set(40, 5, lmin=4000, lmax=7000, fam=5)
-    seqs[7] = np.concatenate([seqs[7][:1000], np.full(20, 5, np.uint8), seqs[7][1000:]])
-    for prm in (None, dict(mal=13, msl=8, reg=30)):
-        assert np.array_equal(gpu_all2all(seqs, prm), O.oracle_all2all(seqs, prm, threads=16))
+def test_multi_batch_path(monkeypatch):
+    """More reference rows than index slabs (LZANI_MAX_SLOTS=3 forces it; at full size it is the 5 Mbp and the
+    100k-genome configurations that batch): dense, ragged/sparse and alignment runs over several batches equal the
+    oracle and the single-batch run."""
+    _, seqs = SG.make_set(26, 12, lmin=3000, lmax=6000, fam=5)
+    seqs[4] = np.concatenate([seqs[4][:700], np.full(25, 5, np.uint8), seqs[4][700:]])
+    want = O.oracle_all2all(seqs, None, threads=16)
+    n = len(seqs)
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    single = eng.all2all()
+    assert eng.layout()["batches_last_run"] == 1
+    ref_ids, row_off = L.dense_rows(n)
+    one_regs = eng.run_rows_regions(ref_ids, row_off, None)[1]
+    eng.close()
+    assert np.array_equal(single, want)
+
+    monkeypatch.setenv("LZANI_MAX_SLOTS", "3")
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    got = eng.all2all()
+    lay = eng.layout()
+    assert lay["slots"] == 3 and lay["batches_last_run"] == 9
+    assert np.array_equal(got, want)
+    # ragged rows: empty rows, repeated references, rows that straddle batch boundaries
+    st = SG.Stream(31)
+    rr, off, q = [], [0], []
+    for k in range(23):
+        r = st.randint(0, n - 1)
+        cnt = 0 if k % 6 == 1 else st.randint(1, 15)
+        rr.append(r)
+        for _ in range(cnt):
+            x = st.randint(0, n - 1)
+            q.append(x if x != r else (x + 1) % n)
+        off.append(len(q))
+    flat = eng.run_rows(rr, off, q)
+    assert eng.layout()["batches_last_run"] == 8
+    e = 0
+    for row, r in enumerate(rr):
+        for x in q[off[row]:off[row + 1]]:
+            assert flat[e].tolist() == want[r, x].tolist(), (row, r, x)
+            e += 1
+    # the alignment instantiation across batches: same regions as the single-batch run
+    out, regs = eng.run_rows_regions(ref_ids, row_off, None)
+    assert eng.layout()["batches_last_run"] == 9
+    eng.close()
+    assert np.array_equal(out.reshape(-1, 3), want[~np.eye(n, dtype=bool)])
+    assert len(regs) == len(one_regs) and np.array_equal(regs, one_regs)
+
+
+def test_more_rows_than_grid_limit():
+    """70,000 reference rows in one call: beyond the 65,535 slabs one batch can have (the hard limit BASELINE
+    configs[4] with its 100,000 genomes runs into) -- sparse one-query rows over tiny genomes, against the oracle."""
+    st = SG.Stream(606)
+    base = [(st.u64(st.randint(90, 160)) % np.uint64(4)).astype(np.uint8) for _ in range(500)]
+    for k in range(0, 500, 5):                                   # make some pairs related so that the results are not all zero
+        base[k + 1] = SG.mutate(base[k], 0.03, st)
+    n_rows = 70_000
+    ref_ids = np.array([st.randint(0, 499) for _ in range(n_rows)], dtype=np.uint32)
+    q = np.array([(int(r) // 5 * 5 + 1) if int(r) % 5 == 0 and k % 3 == 0 else (int(r) + 1 + k % 498) % 500 for k, r in enumerate(ref_ids)], dtype=np.uint32)
+    assert (q != ref_ids).all()
+    row_off = np.arange(n_rows + 1, dtype=np.uint64)
+    eng = L.Engine()
+    eng.set_genomes(base)
+    got = eng.run_rows(ref_ids, row_off, q)
+    lay = eng.layout()
+    eng.close()
+    assert lay["slots"] == 65535 and lay["batches_last_run"] == 2
+    full = O.oracle_all2all(base, None, threads=16)
+    assert np.array_equal(got, full[ref_ids, q])
+    assert (got[:, 0] > 0).sum() > 1000
+
+
+def test_full_size_10k_genomes():
+    """BASELINE configs[2] at full size on one GPU (10,000 x ~40 kbp, 99,990,000 directed pairs -- the
+    configuration the headline metric is quoted on): size-independent properties over every pair and exact
+    agreement with the oracle on 600 seeded pairs."""
+    n = 10_000
+    names, seqs = SG.make_set_cached(n, 2)
+    lens = np.array([len(s) for s in seqs])
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    ref_ids, row_off = L.dense_rows(n)
+    flat = eng.run_rows(ref_ids, row_off, None).reshape(n, n - 1, 3)
+    lay = eng.layout()
+    eng.close()
+    assert lay["tag_words"] == 1 and lay["n_free"] == 1 and lay["batches_last_run"] == 1
+    mat, lit, comp = flat[..., 0], flat[..., 1], flat[..., 2]
+    assert flat.min() >= 0
+    assert np.array_equal(comp == 0, (mat == 0) & (lit == 0))
+    assert (mat + lit >= 35 * comp).all()                         # a region needs >= reg symbols ...
+    qlen = np.empty((n, n - 1), dtype=np.int64)                  # ... and cannot cover more than the query text
+    for r in range(n):
+        qlen[r, :r] = lens[:r]
+        qlen[r, r:] = lens[r + 1:]
+    assert (mat + lit <= qlen + 40).all()
+    # family structure: every member aligns over most of its length against its family's ancestor (member 0)
+    idx = np.arange(n)
+    fam0 = idx // 10 * 10
+    rel = idx != fam0
+    col = np.where(idx < fam0, idx, idx - 1)                      # column of query idx in row fam0 (idx > fam0 always here)
+    assert (mat[fam0[rel], col[rel]] > 0.5 * lens[idx[rel]]).all()
+    # unrelated random genomes share only chance matches
+    other = (idx + 5000) % n
+    ocol = np.where(idx < other, idx, idx - 1)
+    assert (mat[other, ocol] < 0.05 * lens).all()
+    # checksum of checksums: reproducible across runs of the same set (recorded in DESIGN.md)
+    print("10k checksum", int(mat.sum(dtype=np.int64)), int(lit.sum(dtype=np.int64)), int(comp.sum(dtype=np.int64)))
+    st = SG.Stream(2024)
+    pairs = [(st.randint(0, n - 1), st.randint(0, n - 1)) for _ in range(400)]
+    pairs += [(10 * (k * 37 % 1000), 10 * (k * 37 % 1000) + 1 + k % 9) for k in range(200)]          # related pairs
+    for r, q in pairs:
+        if r != q:
+            assert tuple(flat[r, q if q < r else q - 1]) == O.oracle_pair(seqs[r], seqs[q]), (r, q)
+
+
+def test_bacterial_geometry_5mbp():
+    """BASELINE configs[3] at its own geometry: 5 Mbp genomes with --mal 15 --msl 9 --reg 60 -> 30 key bits, 2^24
+    buckets, 24-bit positions, 6 tag bits, i.e. tag words + a 256 MB bucket table per slab and the
+    global-atomics index build; the whole 5 x 5 matrix against the oracle."""
+    st = SG.Stream(303)
+    anc = (st.u64(5_000_000) % np.uint64(4)).astype(np.uint8)
+    other = (st.u64(4_700_000) % np.uint64(4)).astype(np.uint8)
+    seqs = [anc, SG.mutate(anc, 0.01, st), SG.mutate(anc, 0.06, st), other, SG.mutate(other, 0.03, st)]
+    prm = dict(mal=15, msl=9, reg=60)
+    eng = L.Engine(prm)
+    eng.set_genomes(seqs)
+    lay = eng.layout()
+    assert (lay["key_bits"], lay["dir_bits"], lay["pos_bits"], lay["tag_mask"]) == (30, 24, 24, 0x3F)
+    assert lay["kmer_words"] == 1 and lay["bucket_table"] == 1 and lay["tag_words"] == 1
+    got = eng.all2all()
+    assert eng.layout()["bytes_per_slot"] > 400 << 20
+    eng.close()
+    want = O.oracle_all2all(seqs, prm, threads=16)
+    bad = np.argwhere((got != want).any(axis=2))
+    assert len(bad) == 0, (bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
+    assert got[0, 1, 0] > 4_500_000 and got[3, 4, 0] > 4_000_000 and got[0, 3, 0] < 1_000_000
+
+
+def test_device_group_single_process(monkeypatch):
+    """lzani_group_* (what `lz-ani --gpus n` calls): rows partitioned over the devices of the group (cyclic for dense
+    rows, LPT for filtered ones), one context and host thread per device, shards gathered on the first device,
+    restored to the caller's CSR order there, one copy out.  On this one-GPU box the group lists device 0 three
+    times (a rehearsal: shards move by device copies instead of ncclSend/ncclRecv); results must equal the plain
+    single-context run and the oracle."""
+    _, seqs = SG.make_set(31, 19, lmin=3000, lmax=7000, fam=6)
+    want = O.oracle_all2all(seqs, None, threads=16)
+    n = len(seqs)
+    for devs in ((0,), (0, 0, 0)):
+        grp = L.Group(None, devs)
+        grp.set_genomes(seqs)
+        ref_ids, row_off = L.dense_rows(n)
+        flat = grp.run_rows(ref_ids, row_off, None)
+        assert np.array_equal(flat, want[~np.eye(n, dtype=bool)]), devs
+        # filtered rows with very unequal sizes, unsorted, some empty
+        st = SG.Stream(77)
+        rr, off, q = [], [0], []
+        for k in range(40):
+            r = st.randint(0, n - 1)
+            cnt = 0 if k % 7 == 3 else (25 if k % 9 == 0 else st.randint(1, 4))
+            rr.append(r)
+            for _ in range(cnt):
+                x = st.randint(0, n - 1)
+                q.append(x if x != r else (x + 1) % n)
+            off.append(len(q))
+        got = grp.run_rows(rr, off, q)
+        e = 0
+        for row, r in enumerate(rr):
+            for x in q[off[row]:off[row + 1]]:
+                assert got[e].tolist() == want[r, x].tolist(), (devs, row, r, x)
+                e += 1
+        tms = [grp.timing(d) for d in range(len(devs))]
+        assert sum(t["pairs"] for t in tms) == len(q)
+        if len(devs) > 1:
+            assert all(t["pairs"] > 0 for t in tms)
+        assert grp.run_rows([], [0], None).shape == (0, 3)
+        grp.close()
+
+
+def test_rccl_communicator_single_rank():
+    """lzani_comm_* with a one-rank communicator: the library's own RCCL calls (ncclGetUniqueId, ncclCommInitRank,
+    ncclAllGather, grouped ncclSend/ncclRecv path of the root) run on this box; the N > 1 data movement is covered
+    on CPU by tests/test_dist.py and measured by the driver's scaling bench."""
+    import torch
+    _, seqs = SG.make_set(9, 3, lmin=2000, lmax=3000, fam=3)
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    eng.comm_init(1, 0, L.comm_unique_id())
+    n = len(seqs)
+    ref_ids, row_off = L.dense_rows(n)
+    shard = torch.zeros(n * (n - 1) * 3, dtype=torch.int32, device="cuda")
+    recv = torch.full_like(shard, -1)
+    eng.run_rows_device(ref_ids, row_off, None, shard.data_ptr())
+    eng.comm_allgather(shard.data_ptr(), recv.data_ptr(), n * (n - 1))
+    want = O.oracle_all2all(seqs, None, threads=4)[~np.eye(n, dtype=bool)]
+    assert np.array_equal(recv.cpu().numpy().reshape(-1, 3), want)
+    recv.fill_(-1)
+    eng.comm_gatherv(shard.data_ptr(), recv.data_ptr(), [n * (n - 1)], root=0)
+    assert np.array_equal(recv.cpu().numpy().reshape(-1, 3), want)
+    with pytest.raises(L.LzaniError, match="LZANI_ERR_STATE"):
+        eng.comm_init(1, 0, L.comm_unique_id())
+    eng.close()
 
 
 def test_degenerate_inputs():

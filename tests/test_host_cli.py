@@ -235,3 +235,70 @@ def test_end_to_end_on_gpu(tmp_path):
     gold = open(os.path.join(U.GOLD, "example", "ani.aln.tsv")).read().split("\n")
     assert got[0] == gold[0] and sorted(got[1:]) == sorted(gold[1:])
     assert open(out).read() == open(os.path.join(U.GOLD, "example", "ani.tsv")).read()
+
+
+def _synth5(tmp_path, n, seed, lmin, lmax, maxfam):
+    """tools/synth5.cpp: heavy-tailed families + kmer-db filter file + binary sidecar of the codes."""
+    import json
+    exe = str(tmp_path / "synth5")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(U.ROOT, "tools", "synth5.cpp")])
+    fa, flt, side = str(tmp_path / "c5.fna"), str(tmp_path / "c5.flt"), str(tmp_path / "c5.bin")
+    info = json.loads(subprocess.check_output([exe, str(n), str(seed), str(lmin), str(lmax), fa, flt, side, str(maxfam), "0.3"]))
+    hdr = np.fromfile(side, dtype=np.uint64, count=n + 2)
+    assert int(hdr[0]) == n
+    off = hdr[1:].astype(np.int64)
+    codes = np.memmap(side, dtype=np.uint8, mode="r", offset=8 * (n + 2))
+    return fa, flt, info, lambda i: np.array(codes[off[i]:off[i + 1]])
+
+
+def test_synth5_filter_file_format(tmp_path):
+    """CPU: the config-5 generator writes what CFilter::load_filter reads (filter.cpp:34-42, 61-81): header with
+    the names, rows `name,idx:val,...,` with 1-based indices of earlier genomes; the host binary's own filter
+    reader reports 2 x kept pairs."""
+    fa, flt, info, seq = _synth5(tmp_path, 300, 9, 800, 1200, 60)
+    lines = open(flt).read().split("\n")
+    names = lines[0].split(",")
+    assert names[0].startswith("kmer-length:") and names[-1] == "" and len(names) == 302
+    kept = 0
+    for i, ln in enumerate(lines[1:301]):
+        parts = ln.split(",")
+        assert parts[0] == names[1 + i] and parts[-1] == ""
+        for it in parts[1:-1]:
+            idx, val = it.split(":")
+            assert 1 <= int(idx) <= i
+            kept += float(val) >= 0.3
+    assert kept == info["pairs_kept"] and info["genomes"] == 300
+    # through the host binary's reader (matching stage skipped: empty results-in)
+    raw = tmp_path / "raw.txt"
+    raw.write_text("")
+    p = run(["all2all", "--in-fasta", fa, "-o", str(tmp_path / "o.tsv"), "--flt-kmerdb", flt, "0.3", "--results-in", str(raw)])
+    assert p.returncode == 0 and f"Filter size: {2 * kept}" in p.stderr, p.stderr[-400:]
+
+
+@pytest.mark.gpu
+def test_config5_heavy_tailed_filter_20k_genomes(tmp_path):
+    """BASELINE configs[4] shape through the whole binary: 20,000 genomes of ~40 kbp in heavy-tailed families
+    (40 % singletons ... 5 % of 101-1000 members) with a synthetic kmer-db file, --flt-kmerdb at 0.3: the filter
+    size is twice the kept pairs, every kept pair appears in both directions, and sampled rows equal the oracle."""
+    n = 20_000
+    fa, flt, info, seq = _synth5(tmp_path, n, 4, 36000, 44000, 1000)
+    out = str(tmp_path / "ani.tsv")
+    p = run(["all2all", "--in-fasta", fa, "-o", out, "--flt-kmerdb", flt, "0.3", "-V", "2",
+             "--out-format", "query,reference,nt_match,nt_mismatch,num_alns"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert f"Filter size: {2 * info['pairs_kept']}" in p.stderr
+    assert info["largest_row"] > 500
+    import collections
+    rows = collections.Counter()
+    sample = []
+    with open(out) as f:
+        assert f.readline().rstrip("\n") == "query\treference\tnt_match\tnt_mismatch\tnum_alns"
+        for k, ln in enumerate(f):
+            rows["lines"] += 1
+            if (k * 2654435761) % 2**32 < 2**32 // 20000:                 # ~1 line in 20,000
+                sample.append(ln.rstrip("\n").split("\t"))
+    assert rows["lines"] == 2 * info["pairs_kept"]
+    assert len(sample) > 200
+    for qn, rn, mat, lit, aln in sample[:400]:
+        qi, ri = int(qn[1:7]), int(rn[1:7])
+        assert O.oracle_pair(seq(ri), seq(qi)) == (int(mat), int(lit), int(aln)), (qn, rn)

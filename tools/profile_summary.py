@@ -32,12 +32,15 @@ def main(out):
                 a = acc.setdefault(k, [set(), 0.0])
                 a[0].add(r["Dispatch_Id"])
                 a[1] += float(r["Counter_Value"])
-    pairs = None
+    pairs, workload = None, {"genomes": None, "seed": None, "slab_rows": None}
     try:
         with open(os.path.join(out, "stats.log")) as fh:
             for line in fh:
                 if line.startswith("{") and '"config"' in line:
-                    pairs = json.loads(line)["config"].get("pairs_per_step")
+                    cfg = json.loads(line)["config"]
+                    pairs = cfg.get("pairs_per_step")          # one k_pairs launch = one step = one slab
+                    workload = {"genomes": cfg.get("genomes"), "seed": cfg.get("seed"), "slab_rows": cfg.get("slab_rows"),
+                                "params": "default" if cfg.get("params", {}).get("mal") == 11 else cfg.get("params")}
     except Exception:
         pass
     with open(os.path.join(out, "pmc.csv"), "w", newline="") as fh:
@@ -53,7 +56,7 @@ def main(out):
     if fetch and write:
         rec = {
             "source": "tools/profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per k_pairs launch",
-            "workload": {"genomes": 1000, "seed": 1, "params": "default"},
+            "workload": workload,
             "FETCH_SIZE_KB": fetch[0], "WRITE_SIZE_KB": write[0],
             "correction": "gfx950: FETCH_SIZE counts 64 B per 128 B request on wide streaming reads "
                           "(MI355X_MICROARCH.md, HBM); this kernel's reads are 4-16 B per lane, uncalibrated, "

@@ -94,6 +94,33 @@ def make_set(n, seed, lmin=36000, lmax=44000, fam=10, dmin=0.01, dmax=0.15):
     return names, seqs
 
 
+def make_set_cached(n, seed, cache_dir=None, **kw):
+    """make_set through an on-disk cache (one .npz per argument set): the 10,000-genome bench set takes ~1 min
+    to generate, and a profiling session runs the bench many times on one box."""
+    import os
+    cache_dir = cache_dir or os.environ.get("LZANI_SYNTH_CACHE", "/tmp/lzani_synth_cache")
+    key = "set_n%d_s%d_%s.npz" % (n, seed, "_".join("%s%s" % (k, kw[k]) for k in sorted(kw)))
+    path = os.path.join(cache_dir, key)
+    try:
+        z = np.load(path)
+        off, codes = z["off"], z["codes"]
+        seqs = [codes[off[i]:off[i + 1]] for i in range(n)]
+        return [str(x) for x in z["names"]], seqs
+    except Exception:
+        pass
+    names, seqs = make_set(n, seed, **kw)
+    try:
+        os.makedirs(cache_dir, exist_ok=True)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        tmp = path + ".%d.tmp.npz" % os.getpid()
+        np.savez(tmp, off=off, codes=np.concatenate(seqs) if n else np.zeros(0, np.uint8), names=np.array(names))
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return names, seqs
+
+
 def write_fasta(path, names, seqs, width=70):
     lut = np.frombuffer(b"ACGTNN", dtype=np.uint8)
     with open(path, "wb") as f:
