@@ -440,8 +440,11 @@ LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool
 // Wave policy W must provide (all results wave-uniform):
 //   u64  mism_fwd(q0, r0, n)       bit j (j<n) = 1 iff Q[q0+j] does not match R[r0+j]
 //   u64  mism_bwd(q0, r0, n)       bit j (j<n) = 1 iff Q[q0-1-j] does not match R[r0-1-j]
-//   bool find_event(i, n, trk, r_end, lit, lane, bpos, blen)
-//                                   first step l in [0,n) whose evaluation gives len >= msl
+//   bool find_event(i, n, trk, r_end, lit, adv, bpos, blen)
+//                                   looks at the steps i .. i+n-1 (n = all that is left of the query; the policy
+//                                   decides how far it looks in one call): true = the first step that hits
+//                                   (evaluation gives len >= msl) is step i+adv; false = the adv >= 1 steps it
+//                                   looked at do not hit
 //   ExtMasks ext_scan(prevB, B, n)
 //   int  best_split(Lm, Rm, to_scan) argmax_s popc(Lm & low(s)) + popc(Rm >> s), last max wins
 //   void mism2(qa, ra, da, na, qb, rb, db, nb, A, B)   two mismatch masks in one fetch: bit j of A = mismatch of
@@ -591,15 +594,18 @@ struct PairMachine {
 
         while (i < iend) {
             if (++rounds > D + 8) { LZ_GUARD_TRIP(3); out[0] = -1; out[1] = i; out[2] = lit; return; }
-            int n = imin(64, iend - i);
-            int lane = 0, bpos = 0, blen = 0;
+            int adv = 0, bpos = 0, blen = 0;
             w.stamp(1);
-            if (!w.find_event(i, n, trk, r_end, lit, lane, bpos, blen)) {
-                i += n; lit += n;
+            const bool hit = w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);
+            i += adv; lit += adv;
+            if (!hit) {
                 if (lit > P.mqd) trk = false;
                 continue;
             }
-            i += lane; lit += lane;
+#if defined(LZANI_EXP) && LZANI_EXP == 1                     // diagnostic build: events found but not processed
+            i += blen; r_end = bpos + blen; lit = 0; trk = true; prev_re = i;
+            continue;
+#endif
             bool strk = trk && lit <= P.mqd;
             int ref_pred = r_end + lit;
             w.stamp(3);

@@ -11,7 +11,13 @@ namespace lzani {
 // ------------------------------------------------------------------------------------------
 // k_pairs: the pair kernel.
 // ------------------------------------------------------------------------------------------
-enum { SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5), SEED_LDS_WORDS = SEED_BM_WORDS, NQUEUES = 8 };
+enum { SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5), NQUEUES = 8 };
+// anchor queue of a wave (tag-word instantiation): up to AQ_CAP resolved candidates, one per lane; candidates are
+// detected ahead of the scan in chunks of 64 query positions, at most AQ_MAXCHUNKS per refill, and compacted
+// through 2 x AQ_LDS_CAND words of LDS (positions, bucket slots)
+enum { AQ_CAP = 64, AQ_MAXCHUNKS = 16, AQ_LANE_CAP = 32, AQ_LDS_CAND = 128, SEED_LDS_WORDS = SEED_BM_WORDS + 2 * AQ_LDS_CAND };
+enum : u32 { AQ_COMPLEX = 0x80000000u, AQ_LONG = 0x40000000u, AQ_POS = 0x3FFFFFFFu };
+enum { AQ_NONE = 0x7FFFFFFF };
 
 // FAST: per-position k-mer words exist;  BK: the bucket table and its tag words exist
 template <bool FAST, bool BK = false>
@@ -28,6 +34,13 @@ struct DevWave {
     lzani_region* reg_out;
     unsigned long long* reg_count;
     unsigned long long reg_cap, pair_e;
+    // Anchor queue (BK instantiation, see find_event): lane k holds the k-th queued candidate of the pair --
+    // its query position, its reference position (| AQ_LONG / AQ_COMPLEX) and its match length (capped at
+    // AQ_LANE_CAP when AQ_LONG is set); q_head .. q_cnt are live, the query is scanned up to scan_pos.
+    int iend = 0;    // steps exist for query positions < iend
+    int scan_pos = 0, q_head = 0, q_cnt = 0;
+    int a_pos = AQ_NONE, a_len = 0;
+    u32 a_ref = 0;
     __device__ __forceinline__ void emit_region(const RegionCoords& c) const
     {
         // one slot per wave without a lane-dependent branch (see the note at the ticket fetch)
@@ -122,17 +135,22 @@ struct DevWave {
     }
     __device__ __forceinline__ bool seed_prefilter(u32 rk0, u32 rk1, u32 qk) const
     {
+        // no lane-dependent branch (each costs two to three scalar instructions of exec-mask bookkeeping and the
+        // kernel is bound by the scalar pipe): a lane without a k-mer ORs nothing into / clears / reads its own
+        // scratch word behind the bitmap (the candidate buffer of refill, dead between refills)
+        const u32 scratch = SEED_BM_WORDS + (u32)lane;
         const u32 b0 = bm_hash(rk0), b1 = bm_hash(rk1), bq = bm_hash(qk);
-        if (rk0 != KM_INVALID) atomicOr(&bitmap[b0 >> 5], 1u << (b0 & 31));
-        if (rk1 != KM_INVALID) atomicOr(&bitmap[b1 >> 5], 1u << (b1 & 31));
+        const bool v0 = rk0 != KM_INVALID, v1 = rk1 != KM_INVALID, vq = qk != KM_INVALID;
+        const u32 w0 = v0 ? b0 >> 5 : scratch, w1 = v1 ? b1 >> 5 : scratch, wq = vq ? bq >> 5 : scratch;
+        atomicOr(&bitmap[w0], v0 ? 1u << (b0 & 31) : 0u);
+        atomicOr(&bitmap[w1], v1 ? 1u << (b1 & 31) : 0u);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        bool hit = false;
-        if (qk != KM_INVALID) hit = (bitmap[bq >> 5] >> (bq & 31)) & 1u;
+        const bool hit = vq & ((bitmap[wq] >> (bq & 31)) & 1u);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (rk0 != KM_INVALID) bitmap[b0 >> 5] = 0;
-        if (rk1 != KM_INVALID) bitmap[b1 >> 5] = 0;
+        bitmap[w0] = 0;
+        bitmap[w1] = 0;
         return hit;
     }
     // window positions idx < lim (the step's own window) whose msl-mer equals the step's (qkl, wave-uniform)
@@ -169,7 +187,7 @@ struct DevWave {
         if (lane < n)
             eval_step(P, R, Q, I, i + lane, trk && (lit + lane <= P.mqd), r_end, lit + lane, bp, bl);
         u64 hit = __ballot(lane < n && bl >= P.msl);
-        if (!hit) return false;
+        if (!hit) { ev_lane = n; return false; }
         ev_lane = ctz64(hit);
         bpos = __builtin_amdgcn_readlane(bp, ev_lane);     // ev_lane is wave-uniform (from the ballot)
         blen = __builtin_amdgcn_readlane(bl, ev_lane);
@@ -193,14 +211,44 @@ struct DevWave {
         }
     }
 
+    // best_anchor of one step by the whole wave, from the bucket table (hql = the step's mixed mal-mer hash,
+    // wave-uniform): the bucket by a scalar load, its entries carrying the tag verified with wave_equal_len.
+    __device__ __forceinline__ void anchor_by_wave(u32 hql, int qp, int& ap, int& al) const
+    {
+        const int tb = I.kb - I.dirbits;
+        const u32 pm = (u32)lowmask(I.posbits), tag = hql & I.tagmask;
+        // the bucket's address is wave-uniform: a scalar load (the table is read-only during the launch)
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 bq;
+        const u64 baddr = (u64)(I.bk + 4 * (u64)(hql >> tb));
+        // (the address through readfirstlane: an "s" operand must be in SGPRs whatever the allocator did)
+        const u64 bsgpr = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(baddr >> 32)) << 32) |
+                          (u32)__builtin_amdgcn_readfirstlane((int)(u32)baddr);
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bq) : "s"(bsgpr) : "memory");
+        const u32 en[4] = {bq.x, bq.y, bq.z, bq.w};
+        if (__builtin_expect(en[3] == BK_OVERFLOW, 0)) {     // the whole bucket (big buckets are not sorted)
+            walk_bucket(hql >> tb, tag, qp, ap, al);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((en[k] >> I.posbits) != tag) continue;
+                const int p = (int)(en[k] & pm);
+                const int m = wave_equal_len(p, qp, 0);
+                if (m >= P.mal && m > al) { al = m; ap = p; }
+            }
+        }
+    }
+
     // Fast round (k-mer words available, seed window <= 128): the lanes only DETECT candidates --
     // a bucket entry whose tag equals the step's mal-mer, a window position whose msl-mer equals the
     // step's -- and the wave then verifies the candidates of the first candidate lane together
     // (wave_equal_len), exactly as eval_step would for that step; if that step turns out not to hit
     // (quirk Q1, or mal < msl) the next candidate lane is taken.
-    __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit,
-                                               int& ev_lane, int& bpos, int& blen) const
+    __device__ __forceinline__ bool find_event_round(int i, int n, bool trk, int r_end, int lit,
+                                                     int& ev_lane, int& bpos, int& blen) const
     {
+        n = imin(n, 64);
+        ev_lane = n;                                                 // steps looked at when none hits
         const int nt = trk ? imin(n, P.mqd - lit + 1) : 0;          // lanes [0, nt) are tracking steps
         const int W = nt > 0 ? imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end) : 0;
         const int tb = I.kb - I.dirbits;
@@ -263,27 +311,7 @@ struct DevWave {
             int ap = 0, al = 0;
             const u32 cnt = __builtin_amdgcn_readlane(ac, l);
             if (BK && cnt) {                                         // candidate step: now its bucket is read, by the wave
-                const u32 hql = (u32)__builtin_amdgcn_readlane((int)hq, l), tag = hql & I.tagmask;
-                // the bucket's address is wave-uniform: a scalar load (the table is read-only during the launch)
-                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 bq;
-                const u64 baddr = (u64)(I.bk + 4 * (u64)(hql >> tb));
-                // (the address through readfirstlane: an "s" operand must be in SGPRs whatever the allocator did)
-                const u64 bsgpr = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(baddr >> 32)) << 32) |
-                                  (u32)__builtin_amdgcn_readfirstlane((int)(u32)baddr);
-                asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bq) : "s"(bsgpr) : "memory");
-                const u32 en[4] = {bq.x, bq.y, bq.z, bq.w};
-                if (__builtin_expect(en[3] == BK_OVERFLOW, 0)) {     // the whole bucket (big buckets are not sorted)
-                    walk_bucket(hql >> tb, tag, qp, ap, al);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if ((en[k] >> I.posbits) != tag) continue;
-                        const int p = (int)(en[k] & pm);
-                        const int m = wave_equal_len(p, qp, 0);
-                        if (m >= P.mal && m > al) { al = m; ap = p; }
-                    }
-                }
+                anchor_by_wave((u32)__builtin_amdgcn_readlane((int)hq, l), qp, ap, al);
             } else if (cnt) {
                 const u32 hql = (u32)__builtin_amdgcn_readlane((int)hq, l), tag = hql & I.tagmask;
                 if (__builtin_amdgcn_readlane((int)viadir, l)) {
@@ -318,6 +346,204 @@ struct DevWave {
             }
             if (__builtin_expect(bl >= P.msl, 1)) { ev_lane = l; bpos = bp; blen = bl; return true; }
         }
+        return false;
+    }
+    // ---- anchor queue (tag-word instantiation) ------------------------------------------------------------
+    // Every query position whose mal-mer occurs in the reference (a tag-word hit; the tag is exact, so the
+    // k-mers are equal and the step has an anchor of length >= mal) is a CANDIDATE.  Candidates are found ahead
+    // of the scan, state-free, 64 positions per instruction, compacted in order through LDS and resolved in ONE
+    // lane-parallel pass (lane k resolves candidate k: the bucket entry carrying the tag gives the reference
+    // position, a 32-symbol word compare the match length).  The sequential scan then jumps from candidate to
+    // candidate in lost mode and runs a round only over the <= mqd+1 tracking steps after an event.  Replaces the
+    // rounds of 64 speculative steps with one wave-wide verification per candidate (find_event_round), which stay
+    // for the other index forms.  Host model: tests/model/queue_wave.h.
+    __device__ __forceinline__ void lds_order() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void refill(int from)
+    {
+        u32* const cq = bitmap + SEED_BM_WORDS;
+        const int tb = I.kb - I.dirbits;
+        scan_pos = imax(scan_pos, from);
+        int ncand = 0;
+        for (int ch = 0; ch < AQ_MAXCHUNKS && scan_pos < iend && ncand < AQ_CAP; ++ch) {
+            const int n = imin(64, iend - scan_pos);
+            const int p = scan_pos + lane;
+            const u32 hq = qkL[(u32)p];
+            const bool valid = (lane < n) & (hq != KM_INVALID);
+            const u32 w = I.tw[valid ? hq >> tb : 0u];
+            const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);       // a zero byte = a slot with this tag
+            const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;                 // its lowest flag is exact
+            const bool ovf = w == TW_OVERFLOW;
+            const bool c = valid & ((z != 0) | ovf);
+            const u64 bal = __ballot(c);
+            if (bal) {
+                const int at = ncand + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                const bool cplx = ovf | ((z & (z - 1)) != 0);                   // bucket overflow, or the tag in two slots
+                if (c) {
+                    cq[at] = (u32)p;
+                    cq[AQ_LDS_CAND + at] = cplx ? (u32)AQ_COMPLEX : 4u * (hq >> tb) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
+                }
+                ncand += popc64(bal);
+            }
+            scan_pos += n;
+        }
+        lds_order();
+        q_head = 0;
+        q_cnt = imin(ncand, AQ_CAP);
+        if (__builtin_expect(ncand > AQ_CAP, 0))       // the surplus candidates are detected again by the next refill
+            scan_pos = (int)__builtin_amdgcn_readfirstlane(cq[AQ_CAP]);
+        // resolve: lane k owns candidate k
+        const bool live = lane < q_cnt;
+        const int qp = live ? (int)cq[lane] : 0;
+        const u32 slot = live ? cq[AQ_LDS_CAND + lane] : (u32)AQ_COMPLEX;
+        lds_order();
+        const bool simple = !(slot & AQ_COMPLEX);
+        const int pos = (int)(I.bk[simple ? slot : 0u] & (u32)lowmask(I.posbits));
+        // 32 symbols of both texts from pos / qp on, as one 64-bit word each (funnel of two words, no branch)
+        const u32 wr = (u32)pos >> 5, wq = (u32)qp >> 5;
+        const int sr = (pos & 31) * 2, sq = (qp & 31) * 2;
+        const u64 r0 = R.t2[wr], r1 = R.t2[wr + 1], q0 = Q.t2[wq], q1 = Q.t2[wq + 1];
+        const u64 xr = (r0 >> sr) | ((r1 << 1) << (63 - sr)), xq = (q0 >> sq) | ((q1 << 1) << (63 - sq));
+        const u64 df = xr ^ xq;
+        const u64 d = (df | (df >> 1)) & 0x5555555555555555ULL;
+        int same = d ? (ctz64(d) >> 1) : AQ_LANE_CAP;
+        int bound;
+        if (R.nfree && Q.nfree) bound = imin(run_end(R, pos) - pos, run_end(Q, qp) - qp);
+        else {
+            bound = imin(R.len - pos, Q.len - qp);
+            const u32 nn = (u32)(winN(R.nm, pos) | winN(Q.nm, qp));
+            same = imin(same, nn ? (int)__builtin_ctz(nn) : AQ_LANE_CAP);
+        }
+        const bool lng = (same == AQ_LANE_CAP) & (bound > AQ_LANE_CAP);
+        a_pos = live ? qp : (int)AQ_NONE;
+        a_ref = simple ? ((u32)pos | (lng ? (u32)AQ_LONG : 0u)) : (u32)AQ_COMPLEX;
+        a_len = simple ? imin(same, bound) : 0;
+    }
+    // the queue without the candidates before query position pos
+    __device__ __forceinline__ void drop_before(int pos)
+    {
+        const u64 m = __ballot((lane >= q_head) & (a_pos >= pos));          // lanes beyond q_cnt hold AQ_NONE
+        q_head = m ? ctz64(m) : 64;
+    }
+    // best_anchor of the queued step k (wave-uniform k), exactly
+    __device__ __forceinline__ void anchor_of(int k, int qp, int& ap, int& al) const
+    {
+        const u32 ref = (u32)__builtin_amdgcn_readlane((int)a_ref, k);
+        ap = 0; al = 0;
+        if (__builtin_expect((ref & AQ_COMPLEX) != 0, 0)) {
+            anchor_by_wave((u32)__builtin_amdgcn_readfirstlane((int)qkL[(u32)qp]), qp, ap, al);
+            return;
+        }
+        ap = (int)(ref & AQ_POS);
+        al = __builtin_amdgcn_readlane(a_len, k);
+        if (__builtin_expect((ref & AQ_LONG) != 0, 0)) al = wave_equal_len(ap, qp, AQ_LANE_CAP);
+        // a candidate is a k-mer hit in the genome's REFERENCE text; as a query the text ends at D, and with
+        // mrd < mal - msl a step near the end holds a k-mer that runs past it: shorter than mal = no anchor
+        if (__builtin_expect(al < P.mal, 0)) { ap = 0; al = 0; }
+    }
+
+    __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit, int& adv, int& bpos, int& blen)
+    {
+        if (!FAST || !BK || P.mqd + P.mrd > 128)                     // other index forms, wide seed windows: rounds
+            return find_event_round(i, n, trk, r_end, lit, adv, bpos, blen);
+        int off = 0;
+        if (trk) {                                                   // (the machine clears trk once lit > mqd)
+            // One round over the tracking steps: close seeds as in find_event_round, anchors from the queue.
+            const int nt = imin(imin(n, P.mqd - lit + 1), 64);        // one lane per tracking step
+            drop_before(i);
+            if (scan_pos < i + nt) { scan_pos = i; refill(i); }      // the queue must cover the tracking steps
+            const int W = imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end);
+            u32 rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
+            u64 seedmask = 0;
+            if (W > 0) {
+                const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
+                qk = qkS[(u32)(i + lane)];
+                rk0 = rkS[(u32)(r_end + w0)];
+                rk1 = rkS[(u32)(r_end + w1)];
+                qk = lane < nt ? qk : KM_INVALID;
+                rk0 = lane < W ? rk0 : KM_INVALID;
+                rk1 = lane + 64 < W ? rk1 : KM_INVALID;
+                stamp(2);
+                seedmask = __ballot(seed_prefilter(rk0, rk1, qk));
+            }
+            stamp(7);
+            int guard = 0;
+            // Common case (four rounds out of five of an unrelated pair): no tracking step has a close-seed
+            // candidate.  Then a tracking step can only hit through its anchor, which wins the arbitration unopposed
+            // unless it sits at reference position 0 (quirk Q1): the next event is simply the next queued candidate
+            // that passes this test, whether it is still a tracking step or already a lost one.
+            if (__builtin_expect(seedmask == 0 && lit + nt > P.mqd, 1)) {
+                int pos = i;
+                for (;;) {
+                    if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
+                    if (q_head >= q_cnt) {
+                        if (scan_pos >= iend) break;
+                        refill(pos);
+                        continue;
+                    }
+                    const int qp = __builtin_amdgcn_readlane(a_pos, q_head);
+                    int ap, al;
+                    anchor_of(q_head, qp, ap, al);
+                    ++q_head;
+                    if (__builtin_expect((al >= P.msl) & ((qp - i >= nt) | (ap != 0)), 1)) { adv = qp - i; bpos = ap; blen = al; return true; }
+                    pos = qp + 1;
+                }
+                adv = n;
+                return false;
+            }
+            for (;;) {
+                if (++guard > 130) { LZ_GUARD_TRIP(6); break; }
+                const int ls = seedmask ? ctz64(seedmask) : 64;
+                int la = 64;
+                if (q_head < q_cnt) la = imin(64, __builtin_amdgcn_readlane(a_pos, q_head) - i);
+                if (la >= nt) la = 64;
+                const int l = imin(ls, la);
+                if (l >= 64) break;
+                const int qp = i + l;
+                int ap = 0, al = 0;
+                if (la == l) { anchor_of(q_head, qp, ap, al); ++q_head; }
+                int sp = 0, sl = 0;
+                if (ls == l) {
+                    seedmask &= seedmask - 1;
+                    const int ref_pred = r_end + lit + l;
+                    u64 d0 = 0, d1 = 0;
+                    const u32 qkl = (u32)__builtin_amdgcn_readlane((int)qk, l);
+                    if (qkl != KM_INVALID) seed_candidates(qkl, lit + l + P.mrd, rk0, rk1, d0, d1);
+                    while (d0 | d1) {
+                        int idx;
+                        if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
+                        else { idx = 64 + ctz64(d1); d1 &= d1 - 1; }
+                        seed_consider(r_end + idx, wave_equal_len(r_end + idx, qp, P.msl), ref_pred, sp, sl);
+                    }
+                }
+                arbitrate(P, R.len, lit + l, ap, al, sp, sl);
+                if (sl >= P.msl) { adv = l; bpos = sp; blen = sl; return true; }
+            }
+            if (lit + nt <= P.mqd) { adv = nt; return false; }       // mqd = 64: one more tracking step in the next call
+            off = nt;
+        }
+        // lost mode: jump to the next queued candidate
+        int pos = i + off, guard = 0;
+        for (;;) {
+            if (pos >= i + n) break;
+            if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
+            drop_before(pos);
+            if (q_head >= q_cnt) {
+                if (scan_pos >= iend) break;
+                refill(pos);
+                continue;
+            }
+            const int qp = __builtin_amdgcn_readlane(a_pos, q_head);
+            int ap, al;
+            anchor_of(q_head, qp, ap, al);
+            ++q_head;
+            if (__builtin_expect(al >= P.msl, 1)) { adv = qp - i; bpos = ap; blen = al; return true; }
+            pos = qp + 1;
+        }
+        adv = n;
         return false;
     }
     __device__ __forceinline__ ExtMasks ext_scan(u64 prevB, u64 B, int n) const
@@ -430,6 +656,7 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
                         lds,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
                         FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
+        w.iend = D - Pk.msl;
         PairMachine<DevWave<FAST, BK>, ALN> m(w, Pk, T, D);
         int res[3];
 #ifdef LZANI_STAMPS

@@ -2,6 +2,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before liblzani_hip.so: torch must load its own bundled HIP runtime first (same soname)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("lz-ani_amd", "oracle", "tools", "tests"):

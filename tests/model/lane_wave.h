@@ -119,6 +119,7 @@ struct LaneWave {
     }
     LZ_HD bool find_event(int i, int n, bool trk, int r_end, int lit, int& lane, int& bpos, int& blen) const
     {
+        lane = n;                                          // the steps looked at when none hits: all of them
         for (int l = 0; l < n; ++l) {
             const int qp = i + l;
             int ap = 0, al = 0;

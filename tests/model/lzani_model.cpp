@@ -13,6 +13,7 @@
 #include "../../lz-ani_amd/csrc/lzani_core.h"
 #include "../../lz-ani_amd/csrc/lzani_layout.h"
 #include "lane_wave.h"
+#include "queue_wave.h"
 
 using namespace lzani;
 
@@ -112,13 +113,15 @@ struct HostWave {
         A = da > 0 ? mism_fwd(qa, ra, na) : mism_bwd(qa + 1, ra + 1, na);
         B = db > 0 ? mism_fwd(qb, rb, nb) : mism_bwd(qb + 1, rb + 1, nb);
     }
-    bool find_event(int i, int n, bool trk, int r_end, int lit, int& lane, int& bpos, int& blen) const
+    bool find_event(int i, int n, bool trk, int r_end, int lit, int& adv, int& bpos, int& blen) const
     {
+        n = imin(n, 64);                                   // a round of up to 64 steps, as the device's round path
         for (int l = 0; l < n; ++l) {
             int bp, bl;
             eval_step(P, R, Q, I, i + l, trk && (lit + l <= P.mqd), r_end, lit + l, bp, bl);
-            if (bl >= P.msl) { lane = l; bpos = bp; blen = bl; return true; }
+            if (bl >= P.msl) { adv = l; bpos = bp; blen = bl; return true; }
         }
+        adv = n;
         return false;
     }
     ExtMasks ext_scan(u64 prevB, u64 B, int n) const
@@ -163,6 +166,42 @@ int model_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t* len, 
             if (r == q) { o[0] = o[1] = o[2] = 0; continue; }
             HostWave w{P, G[r].rview(), G[q].qview(), G[r].iv};
             PairMachine<HostWave> m(w, P, G[r].T, G[q].D);
+            int res[3];
+            m.run(res);
+            o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+        }
+    return 0;
+}
+
+// The anchor-queue formulation of the device's find_event (queue_wave.h) on the host: out as model_all2all.
+int model_queue_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t* len, const int32_t* p8, int32_t* out)
+{
+    Params P{p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]};
+    if (!params_supported(P) || P.mal > 15 || P.msl > 15) return -1;
+    uint32_t maxL = 0;
+    for (uint32_t i = 0; i < n; ++i) maxL = std::max(maxL, len[i]);
+    const int Tmax = ref_text_len((int)maxL, P.mrd);
+    IndexGeom geo = index_geometry(Tmax, P.mal);
+    if (geo.tagmask != (u32)lowmask(geo.kb - geo.dirbits)) return -1;        // the queue needs exact tags
+    std::vector<Genome> G(n);
+    std::vector<QueueWaveTables> tabs(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        pack_genome(G[i], codes[i], (int)len[i], P); build_index(G[i], P, geo); build_seed_index(G[i], P, Tmax);
+        const size_t nb = (size_t)1 << geo.dirbits;
+        tabs[i].bk.assign(4 * nb, BK_EMPTY);
+        for (size_t b = 0; b < nb; ++b) {
+            const u32 s = G[i].dirz[b], e = G[i].dirz[b + 1];
+            for (u32 k = 0; k < 4 && s + k < e; ++k) tabs[i].bk[4 * b + k] = G[i].ent[s + k];
+            if (e - s > 4) tabs[i].bk[4 * b + 3] = BK_OVERFLOW;
+        }
+    }
+    for (uint32_t r = 0; r < n; ++r)
+        for (uint32_t q = 0; q < n; ++q) {
+            int32_t* o = out + ((size_t)r * n + q) * 3;
+            if (r == q) { o[0] = o[1] = o[2] = 0; continue; }
+            HostWave base{P, G[r].rview(), G[q].qview(), G[r].iv};
+            QueueWave<HostWave> w(base, tabs[r], G[q].kmL.data(), G[q].D - P.msl);
+            PairMachine<QueueWave<HostWave>> m(w, P, G[r].T, G[q].D);
             int res[3];
             m.run(res);
             o[0] = res[0]; o[1] = res[1]; o[2] = res[2];

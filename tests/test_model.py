@@ -109,3 +109,41 @@ def test_differential_fuzz_models_vs_oracle():
             res, regs = U.model_pair_regions(seqs[r], seqs[q], prm)
             ores, oregs = O.oracle_pair(seqs[r], seqs[q], prm, want_regions=True)
             assert res == ores and np.array_equal(regs, oregs), (it, prm, r, q)
+
+
+def _queue_model(seqs, prm=None):
+    """The anchor-queue formulation of find_event (tests/model/queue_wave.h); None where it does not apply
+    (no k-mer words, or tags that do not identify the k-mer)."""
+    lib = U.model_lib()
+    s, ptrs, lens = O._seq_table(seqs)
+    out = np.zeros((len(s), len(s), 3), dtype=np.int32)
+    rc = lib.model_queue_all2all(len(s), ptrs, O._ptr(lens), O.params_array(prm), O._ptr(out))
+    return out if rc == 0 else None
+
+
+def test_anchor_queue_formulation():
+    """Candidates detected ahead in chunks, resolved lane-serially with a 32-symbol cap, tracking rounds over the
+    tracking steps only and jumps in lost mode: the same events as the reference's step-by-step scan."""
+    _, ex = U.load_example()
+    assert np.array_equal(_queue_model(ex), O.oracle_all2all(ex, None, threads=8))
+    E = U.edge_set()
+    done = 0
+    for prm in list(U.VARIANTS.values()) + EXTRA:
+        got = _queue_model(E, prm)
+        if got is not None:
+            assert np.array_equal(got, O.oracle_all2all(E, prm, threads=8)), prm
+            done += 1
+    assert done >= 10
+    _, seqs = SG.make_set(12, 3, lmin=5000, lmax=9000, fam=4)
+    seqs[2] = np.concatenate([seqs[2][:900], np.full(40, 5, np.uint8), seqs[2][900:]])
+    for prm in (None, dict(mal=15, msl=9, reg=60), dict(mrd=0), dict(mrd=2, mqd=2), dict(mal=9, msl=12, mqd=30)):    # the last: mal < msl
+        assert np.array_equal(_queue_model(seqs, prm), O.oracle_all2all(seqs, prm, threads=8)), prm
+    st = SG.Stream(31337)
+    done = 0
+    for it in range(200):
+        prm, seqs = U.fuzz_case(st)
+        got = _queue_model(seqs, prm)
+        if got is not None:
+            assert np.array_equal(got, O.oracle_all2all(seqs, prm, threads=4)), (it, prm)
+            done += 1
+    assert done > 100
