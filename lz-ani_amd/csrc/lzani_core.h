@@ -436,6 +436,104 @@ LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool
     qual = in && (W >> (64 - a)) == 0;                // the last max(ar,1) symbols all match
 }
 
+// ---- lane-serial forms (one lane works a whole 64-symbol chunk alone) -----------------------------------
+// Used where 64 independent items are at hand -- the candidates of the anchor queue, one per lane
+// (lzani_kernels_pairs.h: refill) -- so that a wave-wide instruction serves 64 of them instead of one.
+LZ_HD u64 compress_even(u64 x)        // bits 0,2,4,.. of x -> bits 0..31
+{
+    x &= 0x5555555555555555ULL;
+    x = (x | (x >> 1)) & 0x3333333333333333ULL;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
+    return x;
+}
+LZ_HD u64 bits_below(int n) { return lowmask(n < 0 ? 0 : n); }       // bits j < n, n clamped to [0,64]
+LZ_HD u64 bits_range(int a, int b) { return bits_below(b) & ~bits_below(a); }
+LZ_HD u64 valid_bits(const TextView& t, int p0)                       // N-free text: bit j = p0 + j is a real symbol
+{
+    u64 v = bits_range(-p0, t.L - p0);
+    if (t.rc0 != NO_RC) v |= bits_range(t.rc0 - p0, t.rc0 + t.L - p0);
+    return v;
+}
+// 32 symbols from p on (p >= 0), branch-free funnel of two words
+LZ_HD u64 win2f(const u64* t2, int p)
+{
+    const u32 w = (u32)p >> 5;
+    const int s = (p & 31) * 2;
+    return (t2[w] >> s) | ((t2[w + 1] << 1) << (63 - s));
+}
+LZ_HD u64 winNf(const u64* nm, int p)
+{
+    const u32 w = (u32)p >> 6;
+    const int s = p & 63;
+    return (nm[w] >> s) | ((nm[w + 1] << 1) << (63 - s));
+}
+// bit j (j < 32) = 1 iff Q[q0+j] does not match R[r0+j] (positions beyond a text, pads and N never match);
+// q0, r0 >= 0
+LZ_HD u32 lane_mism32(const TextView& R, const TextView& Q, int q0, int r0)
+{
+    const u64 x = win2f(R.t2, r0) ^ win2f(Q.t2, q0);
+    const u32 mm = (u32)compress_even(x | (x >> 1));
+    u32 valid;
+    if (R.nfree && Q.nfree) valid = (u32)(valid_bits(R, r0) & valid_bits(Q, q0));
+    else valid = (u32)(~(winNf(R.nm, r0) | winNf(Q.nm, q0)) & bits_below(R.len - r0) & bits_below(Q.len - q0));
+    return mm | ~valid;
+}
+LZ_HD u32 brev32(u32 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x);
+#else
+    u32 r = 0;
+    for (int k = 0; k < 32; ++k) r |= ((x >> k) & 1u) << (31 - k);
+    return r;
+#endif
+}
+LZ_HD int popc32(u32 x) { return popc64((u64)x); }
+
+// "Null extension" record of a queued candidate (query position qp, reference position pos, match length al):
+// what a distant event there needs to know to see, WITHOUT touching the texts, that neither approximate
+// extension moves (try_extend_*, parser.cpp:377-441) -- true for four events out of five of an unrelated pair,
+// whose anchors are chance k-mers with random flanks.  State-free, so computed ahead, by one lane per
+// candidate, for a whole batch of the anchor queue (lzani_kernels_pairs.h: refill).
+//   bits 0..aw-1  backward qual bits (ext_lane: symbol j back and the ar-1 before it all match), j < aw
+//   bit 30        the first aw backward symbols hold more than am mismatches (the scan breaks inside them)
+//   bit 31        the forward extension is provably empty: its first aw symbols break the scan and none qualifies
+// An extension is empty iff no symbol qualifies up to the break; if the first aw symbols already break the scan
+// the later ones do not matter.  A record that proves nothing (aw > 30, a text end nearby) has every qual bit set.
+enum : u32 { EXT_REC_NONE = 0x3FFFFFFFu, EXT_REC_BRKB = 0x40000000u, EXT_REC_NULLF = 0x80000000u };
+LZ_HD u32 ext_qual32(u32 B, int ar)            // qual bits of a chunk's first 32 symbols (no earlier chunk)
+{
+    const int a = ar < 1 ? 1 : ar;
+    const u32 Z = ~B;
+    u32 acc = Z;
+    for (int k = 1; k < a && k < 32; ++k) acc &= (Z << k) | (u32)lowmask(k);      // symbols before the start count as matches
+    return acc;
+}
+LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q, int qp, int pos, int al)
+{
+    if (P.aw > 30) return EXT_REC_NONE;
+    const u32 wm = (u32)lowmask(P.aw);
+    u32 rec = EXT_REC_NONE;
+    if (qp >= 32 && pos >= 32) {                                       // all 32 symbols before the match exist
+        const u32 Bb = brev32(lane_mism32(R, Q, qp - 32, pos - 32));   // bit j = symbol qp-1-j / pos-1-j
+        rec = (ext_qual32(Bb, P.ar) & wm) | (popc32(Bb & wm) > P.am ? (u32)EXT_REC_BRKB : 0u);
+    }
+    const int fq = qp + al, fr = pos + al;
+    if (imin(Q.len - fq, R.len - fr) >= P.aw) {
+        const u32 Bf = lane_mism32(R, Q, fq, fr);
+        if (popc32(Bf & wm) > P.am && (ext_qual32(Bf, P.ar) & wm) == 0) rec |= EXT_REC_NULLF;
+    }
+    return rec;
+}
+// the backward extension over nb symbols is empty, by the record
+LZ_HD bool ext_rec_null_bwd(u32 rec, int nb, int aw)
+{
+    return (rec & (u32)lowmask(imin(nb, aw))) == 0 && (nb <= aw || (rec & EXT_REC_BRKB));
+}
+
 // ---- the pair state machine ------------------------------------------------------------
 // Wave policy W must provide (all results wave-uniform):
 //   u64  mism_fwd(q0, r0, n)       bit j (j<n) = 1 iff Q[q0+j] does not match R[r0+j]
@@ -449,6 +547,8 @@ LZ_HD void ext_lane(u64 prevB, u64 B, int j, int n, int aw, int am, int ar, bool
 //   int  best_split(Lm, Rm, to_scan) argmax_s popc(Lm & low(s)) + popc(Rm >> s), last max wins
 //   void mism2(qa, ra, da, na, qb, rb, db, nb, A, B)   two mismatch masks in one fetch: bit j of A = mismatch of
 //                                   Q[qa + da*j] vs R[ra + da*j] for j < na (d = +1 forward, -1 backward), same for B
+//   bool ext_record(u32&)           the null-extension record (null_ext_record) of the event find_event just
+//                                   returned, if the policy has one (the anchor queue of the device)
 //   void stamp(section)             profiling hook (no-op outside the LZANI_STAMPS diagnostic build)
 //   void emit_region(RegionCoords)  ALN only: one region of calc_regions (length >= reg)
 template <class W, bool ALN = false>
@@ -497,7 +597,7 @@ struct PairMachine {
     }
 
     // try_extend_forward (parser.cpp:377-409) fused with the fold of compare_ranges(i, ref_pred, e)
-    // have0/B0: the mismatch mask of the first chunk, if the caller fetched it already (mism_fb)
+    // have0/B0: the mismatch mask of the first chunk, if the caller fetched it already (mism2)
     LZ_HD int extend_forward(int q0, int r0, bool have0 = false, u64 B0 = 0)
     {
         int maxlen = imin(D - q0, T - r0);
@@ -602,7 +702,7 @@ struct PairMachine {
                 if (lit > P.mqd) trk = false;
                 continue;
             }
-#if defined(LZANI_EXP) && LZANI_EXP == 1                     // diagnostic build: events found but not processed
+#if defined(LZANI_EXP) && LZANI_EXP >= 1                     // diagnostic build: events found but not processed
             i += blen; r_end = bpos + blen; lit = 0; trk = true; prev_re = i;
             continue;
 #endif
@@ -625,11 +725,23 @@ struct PairMachine {
                     if (ALN) c.clear();
                     prev_rs = -1;
                 } else avail = lit;
+                fq = i + blen; fr = bpos + blen;
+                const int nb = avail > 0 ? imax(0, imin(64, imin(avail, imin(i, bpos)))) : 0;
+                u32 rec;
+                if (!ALN && w.ext_record(rec) && (rec & EXT_REC_NULLF) && ext_rec_null_bwd(rec, nb, P.aw)) {
+                    // The null event, by the candidate's record: neither extension moves (a chance k-mer with random
+                    // flanks -- four events out of five of an unrelated pair).  No text access, no lane work: the
+                    // match opens a region on its own.
+                    g.finalize();                                       // a match_distant factor follows
+                    pre_lit = avail; prev_rs = i;
+                    g.seg_match_run(blen);
+                    i += blen; r_end = bpos + blen; lit = 0; trk = true;
+                    prev_re = i;
+                    continue;
+                }
                 // the first chunks of the backward and of the forward extension are fetched together (one
                 // memory wait); the fold of the backward part comes out of the same mask
-                fq = i + blen; fr = bpos + blen;
                 const int nf = imax(0, imin(64, imin(D - fq, T - fr)));
-                const int nb = avail > 0 ? imax(0, imin(64, imin(avail, imin(i, bpos)))) : 0;
                 w.mism2(fq, fr, 1, nf, i - 1, bpos - 1, -1, nb, Bf, Bb);
                 haveF = true;
                 int b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;

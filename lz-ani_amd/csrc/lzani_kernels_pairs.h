@@ -15,7 +15,7 @@ enum { SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5), NQUEUES = 8 }
 // anchor queue of a wave (tag-word instantiation): up to AQ_CAP resolved candidates, one per lane; candidates are
 // detected ahead of the scan in chunks of 64 query positions, at most AQ_MAXCHUNKS per refill, and compacted
 // through 2 x AQ_LDS_CAND words of LDS (positions, bucket slots)
-enum { AQ_CAP = 64, AQ_MAXCHUNKS = 16, AQ_LANE_CAP = 32, AQ_LDS_CAND = 128, SEED_LDS_WORDS = SEED_BM_WORDS + 2 * AQ_LDS_CAND };
+enum { AQ_CAP = 64, AQ_MAXCHUNKS = 32, AQ_LANE_CAP = 32, AQ_LDS_CAND = 128, SEED_LDS_WORDS = SEED_BM_WORDS + 2 * AQ_LDS_CAND };
 enum : u32 { AQ_COMPLEX = 0x80000000u, AQ_LONG = 0x40000000u, AQ_POS = 0x3FFFFFFFu };
 enum { AQ_NONE = 0x7FFFFFFF };
 
@@ -39,6 +39,8 @@ struct DevWave {
     // AQ_LANE_CAP when AQ_LONG is set); q_head .. q_cnt are live, the query is scanned up to scan_pos.
     int iend = 0;    // steps exist for query positions < iend
     int scan_pos = 0, q_head = 0, q_cnt = 0;
+    int last_src = -1;   // queue entry the event just returned came from, if its null-extension record applies
+    u32 a_ext = EXT_REC_NONE;    // lane k: null-extension record of candidate k (lzani_core.h: null_ext_record)
     int a_pos = AQ_NONE, a_len = 0;
     u32 a_ref = 0;
     __device__ __forceinline__ void emit_region(const RegionCoords& c) const
@@ -368,27 +370,41 @@ struct DevWave {
         const int tb = I.kb - I.dirbits;
         scan_pos = imax(scan_pos, from);
         int ncand = 0;
-        for (int ch = 0; ch < AQ_MAXCHUNKS && scan_pos < iend && ncand < AQ_CAP; ++ch) {
-            const int n = imin(64, iend - scan_pos);
-            const int p = scan_pos + lane;
-            const u32 hq = qkL[(u32)p];
-            const bool valid = (lane < n) & (hq != KM_INVALID);
-            const u32 w = I.tw[valid ? hq >> tb : 0u];
-            const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);       // a zero byte = a slot with this tag
-            const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;                 // its lowest flag is exact
-            const bool ovf = w == TW_OVERFLOW;
-            const bool c = valid & ((z != 0) | ovf);
-            const u64 bal = __ballot(c);
-            if (bal) {
-                const int at = ncand + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                const bool cplx = ovf | ((z & (z - 1)) != 0);                   // bucket overflow, or the tag in two slots
-                if (c) {
-                    cq[at] = (u32)p;
-                    cq[AQ_LDS_CAND + at] = cplx ? (u32)AQ_COMPLEX : 4u * (hq >> tb) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
-                }
-                ncand += popc64(bal);
+        // Four chunks of 64 positions per turn: their k-mer words are requested together, then their tag words (two
+        // memory round trips per 256 positions instead of eight), then the candidates are compacted chunk by chunk.
+        // A turn may look beyond iend or find more than the queue takes: the surplus is masked / detected again.
+        for (int turn = 0; turn < AQ_MAXCHUNKS / 4 && scan_pos < iend && ncand < AQ_CAP; ++turn) {
+            u32 hq[4], w[4];
+            bool valid[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hq[c] = qkL[(u32)imin(scan_pos + 64 * c + lane, iend + 63)];     // (the arrays are padded by 128 entries)
+            asm volatile("" : "+v"(hq[0]), "+v"(hq[1]), "+v"(hq[2]), "+v"(hq[3]));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                valid[c] = (scan_pos + 64 * c + lane < iend) & (hq[c] != KM_INVALID);
+                w[c] = I.tw[valid[c] ? hq[c] >> tb : 0u];
             }
-            scan_pos += n;
+            asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (scan_pos >= iend || ncand >= AQ_CAP) break;               // wave-uniform
+                const int p = scan_pos + lane;
+                const u32 x = w[c] ^ ((0x80u | (hq[c] & I.tagmask)) * 0x01010101u);   // a zero byte = a slot with this tag
+                const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;                     // its lowest flag is exact
+                const bool ovf = w[c] == TW_OVERFLOW;
+                const bool cnd = valid[c] & ((z != 0) | ovf);
+                const u64 bal = __ballot(cnd);
+                if (bal) {
+                    const int at = ncand + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                    const bool cplx = ovf | ((z & (z - 1)) != 0);                       // bucket overflow, or the tag in two slots
+                    if (cnd) {
+                        cq[at] = (u32)p;
+                        cq[AQ_LDS_CAND + at] = cplx ? (u32)AQ_COMPLEX : 4u * (hq[c] >> tb) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
+                    }
+                    ncand += popc64(bal);
+                }
+                scan_pos = imin(scan_pos + 64, iend);
+            }
         }
         lds_order();
         q_head = 0;
@@ -420,7 +436,28 @@ struct DevWave {
         const bool lng = (same == AQ_LANE_CAP) & (bound > AQ_LANE_CAP);
         a_pos = live ? qp : (int)AQ_NONE;
         a_ref = simple ? ((u32)pos | (lng ? (u32)AQ_LONG : 0u)) : (u32)AQ_COMPLEX;
-        a_len = simple ? imin(same, bound) : 0;
+        // A PLAIN candidate -- resolved by the lane, an anchor (length >= mal), long enough to be an event (>= msl)
+        // and not at reference position 0 (quirk Q1) -- is an event wherever the scan meets it unopposed: it
+        // carries its length as it is, every other candidate as -1 - length (the jump path tests one sign).
+        const int al0 = simple ? imin(same, bound) : 0;
+        const bool plain = simple & !lng & (al0 >= P.mal) & (al0 >= P.msl) & (pos != 0);
+        a_len = plain ? al0 : -1 - al0;
+        // what a distant event at this candidate needs to see that neither extension moves, worked out now, by the
+        // lane, for the whole batch at once
+        a_ext = (simple & !lng) ? null_ext_record(P, R, Q, qp, pos, al0) : (u32)EXT_REC_NONE;
+    }
+    __device__ __forceinline__ bool ext_record(u32& x) const
+    {
+        if (last_src < 0) return false;
+        x = (u32)__builtin_amdgcn_readlane((int)a_ext, last_src);
+        return true;
+    }
+    // the record of entry k describes the event (bpos, blen) iff the entry is simple and short, an anchor, and the
+    // event is that anchor
+    __device__ __forceinline__ void note_src(int k, int ap, int al, int bpos, int blen)
+    {
+        const u32 ref = (u32)__builtin_amdgcn_readlane((int)a_ref, k);
+        last_src = (!(ref & (AQ_COMPLEX | AQ_LONG)) && al >= P.mal && bpos == ap && blen == al) ? k : -1;
     }
     // the queue without the candidates before query position pos
     __device__ __forceinline__ void drop_before(int pos)
@@ -439,6 +476,7 @@ struct DevWave {
         }
         ap = (int)(ref & AQ_POS);
         al = __builtin_amdgcn_readlane(a_len, k);
+        al = al < 0 ? -1 - al : al;
         if (__builtin_expect((ref & AQ_LONG) != 0, 0)) al = wave_equal_len(ap, qp, AQ_LANE_CAP);
         // a candidate is a k-mer hit in the genome's REFERENCE text; as a query the text ends at D, and with
         // mrd < mal - msl a step near the end holds a k-mer that runs past it: shorter than mal = no anchor
@@ -449,98 +487,103 @@ struct DevWave {
     {
         if (!FAST || !BK || P.mqd + P.mrd > 128)                     // other index forms, wide seed windows: rounds
             return find_event_round(i, n, trk, r_end, lit, adv, bpos, blen);
-        int off = 0;
-        if (trk) {                                                   // (the machine clears trk once lit > mqd)
-            // One round over the tracking steps: close seeds as in find_event_round, anchors from the queue.
-            const int nt = imin(imin(n, P.mqd - lit + 1), 64);        // one lane per tracking step
-            drop_before(i);
-            if (scan_pos < i + nt) { scan_pos = i; refill(i); }      // the queue must cover the tracking steps
-            const int W = imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end);
-            u32 rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
-            u64 seedmask = 0;
-            if (W > 0) {
-                const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
-                qk = qkS[(u32)(i + lane)];
-                rk0 = rkS[(u32)(r_end + w0)];
-                rk1 = rkS[(u32)(r_end + w1)];
-                qk = lane < nt ? qk : KM_INVALID;
-                rk0 = lane < W ? rk0 : KM_INVALID;
-                rk1 = lane + 64 < W ? rk1 : KM_INVALID;
-                stamp(2);
-                seedmask = __ballot(seed_prefilter(rk0, rk1, qk));
-            }
-            stamp(7);
-            int guard = 0;
-            // Common case (four rounds out of five of an unrelated pair): no tracking step has a close-seed
-            // candidate.  Then a tracking step can only hit through its anchor, which wins the arbitration unopposed
-            // unless it sits at reference position 0 (quirk Q1): the next event is simply the next queued candidate
-            // that passes this test, whether it is still a tracking step or already a lost one.
-            if (__builtin_expect(seedmask == 0 && lit + nt > P.mqd, 1)) {
-                int pos = i;
-                for (;;) {
-                    if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
-                    if (q_head >= q_cnt) {
-                        if (scan_pos >= iend) break;
-                        refill(pos);
-                        continue;
-                    }
-                    const int qp = __builtin_amdgcn_readlane(a_pos, q_head);
-                    int ap, al;
-                    anchor_of(q_head, qp, ap, al);
-                    ++q_head;
-                    if (__builtin_expect((al >= P.msl) & ((qp - i >= nt) | (ap != 0)), 1)) { adv = qp - i; bpos = ap; blen = al; return true; }
-                    pos = qp + 1;
-                }
-                adv = n;
-                return false;
-            }
-            for (;;) {
-                if (++guard > 130) { LZ_GUARD_TRIP(6); break; }
-                const int ls = seedmask ? ctz64(seedmask) : 64;
-                int la = 64;
-                if (q_head < q_cnt) la = imin(64, __builtin_amdgcn_readlane(a_pos, q_head) - i);
-                if (la >= nt) la = 64;
-                const int l = imin(ls, la);
-                if (l >= 64) break;
-                const int qp = i + l;
-                int ap = 0, al = 0;
-                if (la == l) { anchor_of(q_head, qp, ap, al); ++q_head; }
-                int sp = 0, sl = 0;
-                if (ls == l) {
-                    seedmask &= seedmask - 1;
-                    const int ref_pred = r_end + lit + l;
-                    u64 d0 = 0, d1 = 0;
-                    const u32 qkl = (u32)__builtin_amdgcn_readlane((int)qk, l);
-                    if (qkl != KM_INVALID) seed_candidates(qkl, lit + l + P.mrd, rk0, rk1, d0, d1);
-                    while (d0 | d1) {
-                        int idx;
-                        if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
-                        else { idx = 64 + ctz64(d1); d1 &= d1 - 1; }
-                        seed_consider(r_end + idx, wave_equal_len(r_end + idx, qp, P.msl), ref_pred, sp, sl);
-                    }
-                }
-                arbitrate(P, R.len, lit + l, ap, al, sp, sl);
-                if (sl >= P.msl) { adv = l; bpos = sp; blen = sl; return true; }
-            }
-            if (lit + nt <= P.mqd) { adv = nt; return false; }       // mqd = 64: one more tracking step in the next call
-            off = nt;
-        }
-        // lost mode: jump to the next queued candidate
-        int pos = i + off, guard = 0;
+        last_src = -1;
+        // tracking steps of this call (the machine clears trk once lit > mqd); one lane per tracking step
+#if defined(LZANI_EXP) && LZANI_EXP >= 2                     // diagnostic build: no tracking rounds at all
+        trk = false;
+#endif
+        const int nt = trk ? imin(imin(n, P.mqd - lit + 1), 64) : 0;
+        int pos = i, guard = 0;
+        drop_before(i);
+        bool refill_now = scan_pos < i + nt;                         // the queue must cover the tracking steps
+        if (refill_now) scan_pos = i;
+        bool round_done = !trk;
         for (;;) {
-            if (pos >= i + n) break;
-            if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
-            drop_before(pos);
-            if (q_head >= q_cnt) {
-                if (scan_pos >= iend) break;
+            if (refill_now) {                                        // (the one call site of refill: it is big)
+                if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
                 refill(pos);
+                refill_now = false;
+            }
+            if (!round_done) {
+                // One round over the tracking steps: close seeds as in find_event_round, anchors from the queue.
+                round_done = true;
+                const int W = imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end);
+                u32 rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
+                u64 seedmask = 0;
+                if (W > 0) {
+                    const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
+                    qk = qkS[(u32)(i + lane)];
+                    rk0 = rkS[(u32)(r_end + w0)];
+                    rk1 = rkS[(u32)(r_end + w1)];
+                    qk = lane < nt ? qk : KM_INVALID;
+                    rk0 = lane < W ? rk0 : KM_INVALID;
+                    rk1 = lane + 64 < W ? rk1 : KM_INVALID;
+                    stamp(2);
+                    seedmask = __ballot(seed_prefilter(rk0, rk1, qk));
+                }
+                stamp(7);
+                // Common case (four rounds out of five of an unrelated pair): no tracking step has a close-seed
+                // candidate.  Then a tracking step can only hit through its anchor, which wins the arbitration
+                // unopposed unless it sits at reference position 0 (quirk Q1): the next event is simply the next
+                // queued candidate that passes this test (below), whether it is still a tracking step or a lost one.
+                if (__builtin_expect(seedmask != 0 || lit + nt <= P.mqd, 0)) {
+                    for (int it = 0; it < 130; ++it) {
+                        const int ls = seedmask ? ctz64(seedmask) : 64;
+                        int la = 64;
+                        if (q_head < q_cnt) la = imin(64, __builtin_amdgcn_readlane(a_pos, q_head) - i);
+                        if (la >= nt) la = 64;
+                        const int l = imin(ls, la);
+                        if (l >= 64) break;
+                        const int qp = i + l;
+                        int ap = 0, al = 0, src = -1;
+                        if (la == l) { anchor_of(q_head, qp, ap, al); src = q_head; ++q_head; }
+                        int sp = 0, sl = 0;
+                        if (ls == l) {
+                            seedmask &= seedmask - 1;
+                            const int ref_pred = r_end + lit + l;
+                            u64 d0 = 0, d1 = 0;
+                            const u32 qkl = (u32)__builtin_amdgcn_readlane((int)qk, l);
+                            if (qkl != KM_INVALID) seed_candidates(qkl, lit + l + P.mrd, rk0, rk1, d0, d1);
+                            while (d0 | d1) {
+                                int idx;
+                                if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
+                                else { idx = 64 + ctz64(d1); d1 &= d1 - 1; }
+                                seed_consider(r_end + idx, wave_equal_len(r_end + idx, qp, P.msl), ref_pred, sp, sl);
+                            }
+                        }
+                        arbitrate(P, R.len, lit + l, ap, al, sp, sl);
+                        if (sl >= P.msl) {
+                            adv = l; bpos = sp; blen = sl;
+                            if (src >= 0) note_src(src, ap, al, sp, sl);
+                            return true;
+                        }
+                    }
+                    if (lit + nt <= P.mqd) { adv = nt; return false; }   // mqd = 64: one more tracking step in the next call
+                    pos = i + nt;
+                }
+            }
+            // jump to the next queued candidate (lost steps; tracking steps of a round without seed candidates);
+            // every queued position is a step (the scan stops at iend)
+            if (__builtin_expect(q_head >= q_cnt, 0)) {
+                if (pos >= i + n || scan_pos >= iend) break;
+                refill_now = true;
                 continue;
             }
             const int qp = __builtin_amdgcn_readlane(a_pos, q_head);
+            const int plen = __builtin_amdgcn_readlane(a_len, q_head);
+            if (__builtin_expect(plen > 0, 1)) {                     // a plain candidate: the event, whatever kind of step it is
+                adv = qp - i; bpos = (int)((u32)__builtin_amdgcn_readlane((int)a_ref, q_head)); blen = plen;
+                last_src = q_head++;
+                return true;
+            }
             int ap, al;
             anchor_of(q_head, qp, ap, al);
             ++q_head;
-            if (__builtin_expect(al >= P.msl, 1)) { adv = qp - i; bpos = ap; blen = al; return true; }
+            if (__builtin_expect((al >= P.msl) & ((qp - i >= nt) | (ap != 0)), 1)) {
+                adv = qp - i; bpos = ap; blen = al;
+                note_src(q_head - 1, ap, al, ap, al);
+                return true;
+            }
             pos = qp + 1;
         }
         adv = n;

@@ -12,18 +12,6 @@ namespace lzani {
 // the match runs, a walk over the mismatch bits for the window break), and the scan advances one
 // step at a time.  A thread-per-pair GPU kernel built on it was measured 8x slower than the wave kernel
 // (rejected experiments) and removed from the product in round 2.
-LZ_HD u64 compress_even(u64 x)        // bits 0,2,4,.. of x -> bits 0..31
-{
-    x &= 0x5555555555555555ULL;
-    x = (x | (x >> 1)) & 0x3333333333333333ULL;
-    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
-    x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
-    return x;
-}
-LZ_HD u64 bits_below(int n) { return lowmask(n < 0 ? 0 : n); }       // bits j < n, n clamped to [0,64]
-LZ_HD u64 bits_range(int a, int b) { return bits_below(b) & ~bits_below(a); }
 // Anchor-style index lookup of the close seeds of one tracking step (replaces the ht_short bucket walk,
 // parser.cpp:548-580): positions p in [r_end, ref_pred + mrd) holding the step's msl-mer, ascending.
 LZ_HD void seed_lookup(const Params& P, const TextView& R, const TextView& Q, const IndexView& S,
@@ -55,13 +43,8 @@ struct LaneWave {
     const u32* qkS;
 
     LZ_HD void stamp(int) const {}
+    LZ_HD bool ext_record(u32&) const { return false; }
 
-    LZ_HD u64 valid_bits(const TextView& t, int p0) const          // bit j: p0 + j is a real symbol position
-    {
-        u64 v = bits_range(-p0, t.L - p0);
-        if (t.rc0 != NO_RC) v |= bits_range(t.rc0 - p0, t.rc0 + t.L - p0);
-        return v;
-    }
     LZ_HD u64 mism_fwd(int q0, int r0, int n) const
     {
         if (n <= 0) return 0;
@@ -76,7 +59,7 @@ struct LaneWave {
             mm |= compress_even(x | (x >> 1)) << k;
         }
         u64 valid;
-        if (R.nfree && Q.nfree) valid = valid_bits(R, r0) & valid_bits(Q, q0);
+        if (R.nfree && Q.nfree) valid = lzani::valid_bits(R, r0) & lzani::valid_bits(Q, q0);
         else valid = ~(winN(R.nm, r0) | winN(Q.nm, q0)) & bits_below(R.len - r0) & bits_below(Q.len - q0);
         return (mm | ~valid) & lowmask(n);
     }

@@ -96,6 +96,7 @@ struct HostWave {
     std::vector<RegionCoords>* regs = nullptr;
     void emit_region(const RegionCoords& c) const { if (regs) regs->push_back(c); }
     void stamp(int) const {}
+    bool ext_record(u32&) const { return false; }
     u64 mism_fwd(int q0, int r0, int n) const
     {
         u64 m = 0;

@@ -34,6 +34,8 @@ struct QueueWave : Base {
     mutable int a_pos[AQ_CAP];
     mutable u32 a_ref[AQ_CAP];    // reference position | flags
     mutable int a_len[AQ_CAP];
+    mutable u32 a_ext[AQ_CAP];     // null-extension record of a simple, short candidate, made at resolve time
+    mutable int last_src = -1;     // queue entry the last event came from, if its record applies
 
     QueueWave(const Base& b, const QueueWaveTables& t, const u32* qk, int iend_) : Base(b), tab(t), qkL(qk), iend(iend_) {}
 
@@ -67,6 +69,19 @@ struct QueueWave : Base {
         const bool lng = n == AQ_LANE_CAP && bound > AQ_LANE_CAP;
         a_ref[k] = (u32)pos | (lng ? (u32)AQ_LONG : 0u);
         a_len[k] = n;
+        a_ext[k] = lng ? (u32)EXT_REC_NONE : null_ext_record(this->P, R, Q, qp, pos, n);
+    }
+    bool ext_record(u32& x) const
+    {
+        if (last_src < 0) return false;
+        x = a_ext[last_src];
+        return true;
+    }
+    // the record of entry k describes the event (bpos, blen) at its step iff the entry is simple and short, long
+    // enough to be an anchor, and the event is its anchor
+    void note_src(int k, int ap, int al, int bpos, int blen) const
+    {
+        last_src = (!(a_ref[k] & (AQ_COMPLEX | AQ_LONG)) && al >= this->P.mal && bpos == ap && blen == al) ? k : -1;
     }
     void refill(int from) const
     {
@@ -104,19 +119,20 @@ struct QueueWave : Base {
     {
         const Params& P = this->P;
         int off = 0;
+        last_src = -1;
         if (trk && lit <= P.mqd) {
             const int nt = imin(n, P.mqd - lit + 1);
             drop_before(i);
             if (scan_pos < i + nt) { scan_pos = i; refill(i); }          // the queue must cover the tracking steps
             for (int l = 0; l < nt; ++l) {
                 const int qp = i + l;
-                int ap = 0, al = 0;
+                int ap = 0, al = 0, src = -1;
                 drop_before(qp);
-                if (head < cnt && a_pos[head] == qp) anchor_of(head, ap, al);
+                if (head < cnt && a_pos[head] == qp) { anchor_of(head, ap, al); src = head; }
                 int sp = 0, sl = 0;
                 seed_search_window(P, this->R, this->Q, qp, r_end, lit + l, sp, sl);
                 arbitrate(P, this->R.len, lit + l, ap, al, sp, sl);
-                if (sl >= P.msl) { adv = l; bpos = sp; blen = sl; return true; }
+                if (sl >= P.msl) { adv = l; bpos = sp; blen = sl; if (src >= 0) note_src(src, ap, al, sp, sl); return true; }
             }
             off = nt;
         }
@@ -133,7 +149,7 @@ struct QueueWave : Base {
             int ap, al;
             anchor_of(head, ap, al);
             ++head;
-            if (al >= P.msl) { adv = qp - i; bpos = ap; blen = al; return true; }
+            if (al >= P.msl) { adv = qp - i; bpos = ap; blen = al; note_src(head - 1, ap, al, ap, al); return true; }
             pos = qp + 1;
         }
     }
