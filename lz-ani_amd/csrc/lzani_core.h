@@ -727,11 +727,13 @@ struct PairMachine {
                 } else avail = lit;
                 fq = i + blen; fr = bpos + blen;
                 const int nb = avail > 0 ? imax(0, imin(64, imin(avail, imin(i, bpos)))) : 0;
-                u32 rec;
-                if (!ALN && w.ext_record(rec) && (rec & EXT_REC_NULLF) && ext_rec_null_bwd(rec, nb, P.aw)) {
-                    // The null event, by the candidate's record: neither extension moves (a chance k-mer with random
-                    // flanks -- four events out of five of an unrelated pair).  No text access, no lane work: the
-                    // match opens a region on its own.
+                // The candidate's record may prove, without touching the texts, that an approximate extension does not
+                // move (a chance k-mer with random flanks: four extensions out of five of an unrelated pair).
+                u32 rec = EXT_REC_NONE;
+                const bool have_rec = !ALN && w.ext_record(rec);
+                const bool null_f = have_rec && (rec & EXT_REC_NULLF), null_b = nb == 0 || (have_rec && ext_rec_null_bwd(rec, nb, P.aw));
+                if (null_f & null_b) {
+                    // the null event: no text access, no lane work; the match opens a region on its own
                     g.finalize();                                       // a match_distant factor follows
                     pre_lit = avail; prev_rs = i;
                     g.seg_match_run(blen);
@@ -739,12 +741,18 @@ struct PairMachine {
                     prev_re = i;
                     continue;
                 }
-                // the first chunks of the backward and of the forward extension are fetched together (one
-                // memory wait); the fold of the backward part comes out of the same mask
-                const int nf = imax(0, imin(64, imin(D - fq, T - fr)));
-                w.mism2(fq, fr, 1, nf, i - 1, bpos - 1, -1, nb, Bf, Bb);
-                haveF = true;
-                int b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;
+                int b = 0;
+                if (null_b | null_f) {
+                    // one side is known to be empty: fetch and scan the other one only
+                    if (!null_b) { Bb = w.mism_bwd(i, bpos, nb); b = extend_backward(i, bpos, avail, true, Bb); }
+                } else {
+                    // the first chunks of the backward and of the forward extension are fetched together (one
+                    // memory wait); the fold of the backward part comes out of the same mask
+                    const int nf = imax(0, imin(64, imin(D - fq, T - fr)));
+                    w.mism2(fq, fr, 1, nf, i - 1, bpos - 1, -1, nb, Bf, Bb);
+                    haveF = true;
+                    b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;
+                }
                 g.finalize();                                           // a match_distant factor follows
                 region_close();
                 if (__builtin_expect(b > 0, 0)) {
@@ -757,6 +765,11 @@ struct PairMachine {
                     prev_rs = i - b;
                 } else { pre_lit = avail; prev_rs = i; }
                 match_run(i, bpos, blen);
+                if (null_f) {                                           // (then !ALN) the forward extension is empty
+                    i += blen; r_end = bpos + blen; lit = 0; trk = true;
+                    prev_re = i;
+                    continue;
+                }
             }
             i += blen;
             r_end = bpos + blen;

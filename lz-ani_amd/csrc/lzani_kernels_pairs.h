@@ -417,7 +417,9 @@ struct DevWave {
         const u32 slot = live ? cq[AQ_LDS_CAND + lane] : (u32)AQ_COMPLEX;
         lds_order();
         const bool simple = !(slot & AQ_COMPLEX);
-        const int pos = (int)(I.bk[simple ? slot : 0u] & (u32)lowmask(I.posbits));
+        // (a lane without a simple candidate must not wander: slot 0 may hold BK_EMPTY, whose position bits point
+        // far beyond the text)
+        const int pos = simple ? (int)(I.bk[simple ? slot : 0u] & (u32)lowmask(I.posbits)) : 0;
         // 32 symbols of both texts from pos / qp on, as one 64-bit word each (funnel of two words, no branch)
         const u32 wr = (u32)pos >> 5, wq = (u32)qp >> 5;
         const int sr = (pos & 31) * 2, sq = (qp & 31) * 2;
