@@ -495,20 +495,35 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
         HIPCHK(c, hipMalloc(&c->d_kmS, total_nm * 64 * 4));
     }
     choose_index_form(c);
-    // stage the codes through one pinned-size host buffer per chunk of genomes
+    // The caller's sequences are separate host buffers: they go up through two pinned 64 MB staging buffers, the
+    // copy of one overlapping the fill of the other (the 4 GB of config 5 take as long as the PCIe link needs).
     {
-        std::vector<uint8_t> stage;
-        const u64 chunk = 256ull << 20;
-        u32 g = 0;
-        while (g < n) {
-            u32 g1 = g; u64 bytes = 0;
-            while (g1 < n && (bytes == 0 || bytes + len[g1] <= chunk)) { bytes += len[g1]; ++g1; }
-            stage.resize(bytes);
-            u64 o = 0;
-            for (u32 k = g; k < g1; ++k) { if (len[k]) memcpy(stage.data() + o, codes[k], len[k]); o += len[k]; }
-            if (bytes) HIPCHK(c, hipMemcpy(d_codes.p + codeoff[g], stage.data(), bytes, hipMemcpyHostToDevice));
-            g = g1;
+        const u64 chunk = 64ull << 20;
+        uint8_t* pin[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            e = hipHostMalloc((void**)&pin[k], chunk, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
         }
+        u64 at = 0;                                               // codes staged so far
+        u32 g = 0; u64 goff = 0;                                  // next genome / offset inside it
+        for (int k = 0; e == hipSuccess && at < total_codes; k ^= 1) {
+            e = hipEventSynchronize(done[k]);                     // the previous copy out of this buffer (no-op the first time)
+            u64 fill = 0;
+            while (g < n && fill < chunk) {
+                const u64 take = std::min<u64>(chunk - fill, (u64)len[g] - goff);
+                if (take) memcpy(pin[k] + fill, codes[g] + goff, take);
+                fill += take; goff += take;
+                if (goff == len[g]) { ++g; goff = 0; }
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(d_codes.p + at, pin[k], fill, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(done[k], c->stream);
+            at += fill;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        for (int k = 0; k < 2; ++k) { if (done[k]) hipEventDestroy(done[k]); if (pin[k]) hipHostFree(pin[k]); }
+        if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? LZANI_ERR_NOMEM : LZANI_ERR_DEVICE, std::string("staging the sequences: ") + hipGetErrorString(e));
     }
     HIPCHK(c, hipMemcpy(d_codeoff, codeoff.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_nmoff, c->nmoff.data(), (size_t)n * 8, hipMemcpyHostToDevice));

@@ -319,29 +319,36 @@ inline bool store_results(const std::vector<Genome>& g, const PairTable& T, cons
         ofs << "\n";
     }
 
-    // formatter threads fill per-row strings in blocks; the main thread writes them in row order
+    // Formatter threads fill the row strings of one block while the writer thread puts the previous block on disk,
+    // in row order; two blocks of a few rows per thread are all that is ever held (a 10,000-genome row is ~1.8 MB of
+    // text, the whole file 9 GB).
     const std::vector<Cut> cuts = make_cuts(ep);
     const size_t n = T.n;
-    const size_t block = 256;
-    std::vector<std::string> text(std::min(n, block * 64));
-    for (size_t base = 0; base < n; base += text.size()) {
-        size_t cnt = std::min(text.size(), n - base);
+    const uint32_t nt = std::max<uint32_t>(1, ep.threads);
+    const size_t block = std::max<size_t>(8, 4 * (size_t)nt);
+    std::vector<std::string> text[2];
+    text[0].resize(std::min(n, block)); text[1].resize(std::min(n, block));
+    std::thread writer;
+    for (size_t base = 0, k2 = 0; base < n; base += block, k2 ^= 1) {
+        const size_t cnt = std::min(block, n - base);
+        std::vector<std::string>& buf = text[k2];
         std::atomic<size_t> next{0};
         auto worker = [&]() {
             for (;;) {
                 size_t k = next.fetch_add(1);
                 if (k >= cnt) break;
-                text[k].clear();
-                format_row(g, len, T, ep, cuts, (uint32_t)(base + k), text[k]);
+                buf[k].clear();
+                format_row(g, len, T, ep, cuts, (uint32_t)(base + k), buf[k]);
             }
         };
         std::vector<std::thread> th;
-        uint32_t nt = std::max<uint32_t>(1, std::min<uint32_t>(ep.threads, (uint32_t)cnt));
-        for (uint32_t t = 1; t < nt; ++t) th.emplace_back(worker);
+        for (uint32_t t = 1; t < std::min<uint32_t>(nt, (uint32_t)cnt); ++t) th.emplace_back(worker);
         worker();
         for (auto& t : th) t.join();
-        for (size_t k = 0; k < cnt; ++k) ofs.write(text[k].data(), (std::streamsize)text[k].size());
+        if (writer.joinable()) writer.join();                  // the block before this one is on disk: its buffer is free again
+        writer = std::thread([&ofs, &buf, cnt]() { for (size_t k = 0; k < cnt; ++k) ofs.write(buf[k].data(), (std::streamsize)buf[k].size()); });
     }
+    if (writer.joinable()) writer.join();
     ofs.close();
     return true;
 }

@@ -38,8 +38,123 @@ inline const uint8_t* dna_code_table()
     return t;
 }
 
-// Whole file into memory; gzread reads plain files transparently, so .gz and plain share one path
-// (the reference sniffs the gzip magic, file_wrapper.h:541-550).
+// Streaming FASTA parser: the file goes through a 4 MB gzread window (gzread reads plain files transparently, so
+// .gz and plain share one path; the reference sniffs the gzip magic, file_wrapper.h:541-550) and every base is
+// turned into its symbol code where it lands -- no whole-file buffer, no text copy of a sequence.
+// Line rules are those of the reference's stream_decompression::getline users: lines split at '\n', ONE trailing
+// '\r' dropped, empty lines ignored, a line is a header iff its first byte is '>'.
+struct FastaParser {
+    std::vector<Genome>& out;
+    const bool multisample;          // one item per '>' record (seq_reservoir.cpp:156-212) or one per file (90-153)
+    const uint32_t sep_len;          // single-sample mode: N symbols between the contigs of a file
+    const uint8_t* code = dna_code_table();
+    Genome cur;
+    bool have = false;               // a record (multisample) / the file's item (single) is open
+    // line state
+    bool at_line_start = true, in_header = false, pending_cr = false;
+    size_t line_mark = 0;            // cur.codes.size() when the current sequence line began
+    std::string header;
+
+    FastaParser(std::vector<Genome>& o, bool multi, uint32_t sep) : out(o), multisample(multi), sep_len(sep) {}
+
+    void begin_file(const std::string& fn)
+    {
+        at_line_start = true; in_header = false; pending_cr = false; header.clear();
+        if (!multisample) { cur = Genome(); cur.name = std::filesystem::path(fn).filename().string(); have = true; }
+        line_mark = cur.codes.size();
+    }
+    void close_record()
+    {
+        if (have) out.push_back(std::move(cur));
+        cur = Genome(); have = false; line_mark = 0;
+    }
+    void end_header()
+    {
+        if (multisample) {
+            close_record();
+            size_t sp = header.find(' ');
+            cur.name = sp == std::string::npos ? header : header.substr(0, sp);     // cut at the first space (77-81)
+            have = !header.empty();                                                 // a bare '>' opens nothing: what follows it is dropped
+        } else if (!cur.codes.empty()) cur.codes.insert(cur.codes.end(), sep_len, (uint8_t)5);
+        header.clear();
+        in_header = false;
+    }
+    void end_line()
+    {
+        if (in_header) end_header();
+        at_line_start = true; pending_cr = false;
+        line_mark = cur.codes.size();
+    }
+    void put(char c)
+    {
+        if (at_line_start) { at_line_start = false; if (c == '>') { in_header = true; return; } }
+        if (in_header) header.push_back(c);
+        else if (have) cur.codes.push_back(code[(uint8_t)c]);
+    }
+    void feed(const char* p, size_t n)
+    {
+        for (size_t k = 0; k < n; ++k) {
+            const char c = p[k];
+            if (c == '\n') { end_line(); continue; }
+            if (pending_cr) { pending_cr = false; put('\r'); }                      // a '\r' inside a line is a symbol
+            if (c == '\r') { pending_cr = true; continue; }
+            if (!at_line_start && !in_header && have) {
+                // fast path: the rest of a sequence line in one go
+                size_t e = k;
+                while (e < n && p[e] != '\n' && p[e] != '\r') ++e;
+                const size_t at = cur.codes.size();
+                cur.codes.resize(at + (e - k));
+                for (size_t t = k; t < e; ++t) cur.codes[at + (t - k)] = code[(uint8_t)p[t]];
+                k = e - 1;
+                continue;
+            }
+            put(c);
+        }
+    }
+    // end of a file.  Multisample mode never sees a last line without '\n' (the reference's loop gets < 0 from
+    // getline for it, seq_reservoir.cpp:177-178): what it holds is dropped -- and a record whose header line is that
+    // last line does not exist.  Single-sample mode keeps it.
+    void end_file()
+    {
+        if (multisample) {
+            if (!at_line_start) {
+                if (in_header) { header.clear(); in_header = false; }
+                else cur.codes.resize(line_mark);
+            }
+            close_record();
+        } else {
+            if (!at_line_start) { if (pending_cr) { /* trailing '\r' of the last line: dropped like any other */ } end_line(); }
+            close_record();
+        }
+    }
+};
+
+inline bool load_sequences(const std::vector<std::string>& files, bool multisample, uint32_t sep_len, std::vector<Genome>& out)
+{
+    std::vector<char> buf(4u << 20);
+    FastaParser fp(out, multisample, sep_len);
+    for (const auto& fn : files) {
+        gzFile f = gzopen(fn.c_str(), "rb");
+        if (!f) { std::cerr << "Cannot open file: " << fn << std::endl; return false; }
+        gzbuffer(f, 1 << 20);
+        fp.begin_file(fn);
+        for (;;) {
+            int n = gzread(f, buf.data(), (unsigned)buf.size());
+            if (n < 0) { gzclose(f); std::cerr << "Cannot open file: " << fn << std::endl; return false; }
+            if (n == 0) break;
+            fp.feed(buf.data(), (size_t)n);
+        }
+        gzclose(f);
+        fp.end_file();
+    }
+    return true;
+}
+// One item per '>' record (seq_reservoir.cpp:156-212)
+inline bool load_multifasta(const std::vector<std::string>& files, std::vector<Genome>& out) { return load_sequences(files, true, 0, out); }
+// One item per file, contigs joined by `sep_len` N symbols, named after the file (seq_reservoir.cpp:90-153)
+inline bool load_fasta(const std::vector<std::string>& files, uint32_t sep_len, std::vector<Genome>& out) { return load_sequences(files, false, sep_len, out); }
+
+// Whole (small) text file into memory: the kmer-db filter reader below
 inline bool slurp(const std::string& fn, std::string& out)
 {
     gzFile f = gzopen(fn.c_str(), "rb");
@@ -76,62 +191,6 @@ struct LineReader {
         return true;
     }
 };
-
-inline void append_genome(std::vector<Genome>& out, const std::string& name, const std::string& seq)
-{
-    Genome g;
-    size_t sp = name.find(' ');
-    g.name = sp == std::string::npos ? name : name.substr(0, sp);       // cut at the first space (77-81)
-    const uint8_t* t = dna_code_table();
-    g.codes.resize(seq.size());
-    for (size_t i = 0; i < seq.size(); ++i) g.codes[i] = t[(uint8_t)seq[i]];
-    out.push_back(std::move(g));
-}
-
-// One item per '>' record (seq_reservoir.cpp:156-212).  A final line without '\n' is never seen by
-// the reference's loop (getline returns < 0 for it), so it is dropped here too.
-inline bool load_multifasta(const std::vector<std::string>& files, std::vector<Genome>& out)
-{
-    std::string data, line, name, seq;
-    for (const auto& fn : files) {
-        if (!slurp(fn, data)) { std::cerr << "Cannot open file: " << fn << std::endl; return false; }
-        LineReader lr(data);
-        bool term;
-        name.clear(); seq.clear();
-        while (lr.next(line, term)) {
-            if (!term) break;
-            if (line.empty()) continue;
-            if (line.front() == '>') {
-                if (!name.empty()) append_genome(out, name, seq);
-                name.assign(line.begin() + 1, line.end());
-                seq.clear();
-            } else seq.append(line);
-        }
-        if (!name.empty()) append_genome(out, name, seq);
-    }
-    return true;
-}
-
-// One item per file, contigs joined by `sep_len` N symbols, named after the file
-// (seq_reservoir.cpp:90-153).  The unterminated last line is kept in this mode.
-inline bool load_fasta(const std::vector<std::string>& files, uint32_t sep_len, std::vector<Genome>& out)
-{
-    std::string data, line, seq;
-    const std::string separator(sep_len, (char)5);          // code_N_seq bytes; anything non-ACGT maps to N
-    for (const auto& fn : files) {
-        if (!slurp(fn, data)) { std::cerr << "Cannot open file: " << fn << std::endl; return false; }
-        LineReader lr(data);
-        bool term;
-        seq.clear();
-        while (lr.next(line, term)) {
-            if (line.empty()) continue;
-            if (line.front() == '>') { if (!seq.empty()) seq.append(separator); }
-            else seq.append(line);
-        }
-        append_genome(out, std::filesystem::path(fn).filename().string(), seq);
-    }
-    return true;
-}
 
 // reorder_items (seq_reservoir.cpp:215-251): stable sort by (len - 2*no_parts) as uint32 descending,
 // then name ascending; returns old -> new.

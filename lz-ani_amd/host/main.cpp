@@ -488,6 +488,8 @@ static bool run_all2all(const char* argv0)
     stamp("Storing results");
 
     if (P.verbosity > 1) {
+        ifstream st("/proc/self/status");
+        for (string ln; getline(st, ln);) if (ln.rfind("VmHWM:", 0) == 0) cerr << "Peak RSS " << ln.substr(6) << "\n";
         cerr << "Timings\n";
         for (size_t i = 1; i < times.size(); ++i) cerr << times[i].second << " : " << chrono::duration<double>(times[i].first - times[i - 1].first).count() << "s\n";
         cerr << "Total time: " << chrono::duration<double>(times.back().first - times.front().first).count() << "s\n";

@@ -118,6 +118,16 @@ def test_cli_conventions(tmp_path):
     assert p.returncode == 1 and "Cannot open file" in p.stderr
 
 
+def test_parameter_envelope_is_refused_up_front(tmp_path):
+    """The reference accepts any ints for the LZ knobs (lz-ani.cpp:205-260); this engine's wave formulation has an
+    envelope (64-bit lane masks), and the binary says which flag is outside it before it reads any input."""
+    for flag, val in (("--mqd", "100"), ("--aw", "65"), ("--ar", "70"), ("--mal", "40"), ("--msl", "0"), ("--am", "-1")):
+        p = run(["all2all", "--in-fasta", str(tmp_path / "does_not_exist.fna"), "-o", str(tmp_path / "o.tsv"), flag, val])
+        assert p.returncode == 1 and f"Unsupported value: {flag} {val}" in p.stderr, (flag, p.stderr)
+    p = run(["all2all", "--in-fasta", str(tmp_path / "does_not_exist.fna"), "-o", str(tmp_path / "o.tsv"), "--mqd", "64", "--aw", "64"])
+    assert "Unsupported" not in p.stderr and "Cannot open file" in p.stderr
+
+
 def test_ingest_quirks(tmp_path):
     """Name cut at the first space, lower case accepted, CRLF, last unterminated line dropped in
     multi-FASTA mode, contigs joined by mrd N's when --multisample-fasta false (seq_len includes them)."""
@@ -131,6 +141,17 @@ def test_ingest_quirks(tmp_path):
     raw.write_text("")                                            # one item only: no pairs
     assert run(["all2all", "--in-fasta", str(fa), "-o", str(out), "--results-in", str(raw), "--multisample-fasta", "false"]).returncode == 0
     assert (tmp_path / "o.ids.tsv").read_text() == "id\tseq_len\tno_parts\nq.fna\t66\t1\n"       # 16 + 40 + 10
+    # the streaming parser at its seams: bases before the first header and after a bare '>' are dropped, empty lines
+    # and a lone CR line are ignored, a CR inside a line is a symbol (N), an unterminated header line opens nothing
+    fa.write_bytes(b"ACGT\n>a x\nAC\n\n\r\nGT\n>\nTTTT\n>b\nA\rC\nGG\n>c")
+    raw.write_text("0 1 0 0 0\n1 0 0 0 0\n")
+    assert run(["all2all", "--in-fasta", str(fa), "-o", str(out), "--results-in", str(raw)]).returncode == 0
+    assert (tmp_path / "o.ids.tsv").read_text() == "id\tseq_len\tno_parts\nb\t5\t1\na\t4\t1\n"
+    # a file larger than the 4 MB read window, CRLF line ends straddling it
+    big = tmp_path / "big.fna"
+    big.write_bytes(b">x\r\n" + b"ACGTACGTAC\r\n" * 500_000 + b">y\r\nAC\r\n")
+    assert run(["all2all", "--in-fasta", str(big), "-o", str(out), "--results-in", str(raw)]).returncode == 0
+    assert (tmp_path / "o.ids.tsv").read_text() == "id\tseq_len\tno_parts\nx\t5000000\t1\ny\t2\t1\n"
 
 
 def test_number_formatting_against_reference_and_restatement():

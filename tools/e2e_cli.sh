@@ -1,28 +1,23 @@
 #!/bin/bash
-# GPU box: end-to-end wall time of the host binary on a synthetic multi-FASTA.  Usage: tools/e2e_cli.sh [n_genomes]
+# GPU box: end-to-end wall time of the host binary on a synthetic multi-FASTA.  Usage: tools/e2e_cli.sh [n_genomes] [seed] [extra lz-ani args]
 set -o pipefail
-N=${1:-3000}
+N=${1:-3000}; SEED=${2:-2}; shift 2 2>/dev/null
 ROOT=$(pwd)
 D=${TMPDIR:-/tmp}/e2e_$$
 mkdir -p "$D"
-python3 - "$N" "$D/in.fna" <<'PY'
+python3 - "$N" "$SEED" "$D/in.fna" <<'PY'
 import sys
 sys.path.insert(0, "tools")
-import numpy as np, synth_genomes as SG
-n, path = int(sys.argv[1]), sys.argv[2]
-names, seqs = SG.make_set(n, 1)
-lut = np.frombuffer(b"ACGTNN", dtype=np.uint8)
-with open(path, "wb") as f:
-    for k, s in enumerate(seqs):
-        f.write(b">g%06d synthetic\n" % k)
-        a = lut[s]
-        for o in range(0, len(a), 80):
-            f.write(a[o:o + 80].tobytes() + b"\n")
+import synth_genomes as SG
+n, seed, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+names, seqs = SG.make_set_cached(n, seed)
+SG.write_fasta(path, names, seqs)
 print("fasta written:", n, "genomes")
 PY
 ls -la "$D/in.fna" | awk '{print "fasta bytes", $5}'
-"$ROOT/lz-ani_amd/host/lz-ani" all2all --in-fasta "$D/in.fna" --out "$D/out.tsv" --out-ids "$D/ids.tsv" -V 2 > "$D/out.log" 2> "$D/err.log"
+df -h "$D" | tail -1
+"$ROOT/lz-ani_amd/host/lz-ani" all2all --in-fasta "$D/in.fna" --out "$D/out.tsv" --out-ids "$D/ids.tsv" -V 2 "$@" > "$D/out.log" 2> "$D/err.log"
 echo "exit $?"
-tail -12 "$D/out.log"; tail -12 "$D/err.log"
-wc -l "$D/out.tsv" | awk '{print "tsv lines", $1}'; head -3 "$D/out.tsv"
+tail -12 "$D/out.log"; tail -14 "$D/err.log"
+wc -lc "$D/out.tsv" | awk '{print "tsv lines", $1, "bytes", $2}'; head -3 "$D/out.tsv"
 rm -rf "$D"
