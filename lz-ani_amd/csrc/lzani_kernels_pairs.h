@@ -485,50 +485,67 @@ struct DevWave {
         if (__builtin_expect(al < P.mal, 0)) { ap = 0; al = 0; }
     }
 
+    // the close-seed probe of the tracking steps [i, i + nt): which steps have a candidate in their window
+    __device__ __forceinline__ u64 track_round(int i, int nt, int r_end, int lit, u32& rk0, u32& rk1, u32& qk) const
+    {
+        rk0 = rk1 = qk = KM_INVALID;
+        const int W = imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end);
+        if (W <= 0) return 0;
+        const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
+        qk = qkS[(u32)(i + lane)];
+        rk0 = rkS[(u32)(r_end + w0)];
+        rk1 = rkS[(u32)(r_end + w1)];
+        qk = lane < nt ? qk : KM_INVALID;
+        rk0 = lane < W ? rk0 : KM_INVALID;
+        rk1 = lane + 64 < W ? rk1 : KM_INVALID;
+        stamp(2);
+        return __ballot(seed_prefilter(rk0, rk1, qk));
+    }
+
     __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit, int& adv, int& bpos, int& blen)
     {
         if (!FAST || !BK || P.mqd + P.mrd > 128)                     // other index forms, wide seed windows: rounds
             return find_event_round(i, n, trk, r_end, lit, adv, bpos, blen);
         last_src = -1;
         // tracking steps of this call (the machine clears trk once lit > mqd); one lane per tracking step
-#if defined(LZANI_EXP) && LZANI_EXP >= 2                     // diagnostic build: no tracking rounds at all
-        trk = false;
-#endif
         const int nt = trk ? imin(imin(n, P.mqd - lit + 1), 64) : 0;
-        int pos = i, guard = 0;
-        drop_before(i);
+        if (q_head < q_cnt && __builtin_amdgcn_readlane(a_pos, q_head) < i) drop_before(i);
         bool refill_now = scan_pos < i + nt;                         // the queue must cover the tracking steps
-        if (refill_now) scan_pos = i;
         bool round_done = !trk;
+        u32 rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
+        u64 seedmask = 0;
+        if (__builtin_expect(!refill_now, 1)) {
+            // The common call, straight down, no loop: one round over the tracking steps (close seeds as in
+            // find_event_round) and, when none of them has a seed candidate (four rounds out of five of an unrelated
+            // pair), the next queued candidate.  A tracking step can then only hit through its anchor, which wins the
+            // arbitration unopposed unless it sits at reference position 0 (quirk Q1): a PLAIN candidate is the event
+            // whether it is still a tracking step or already a lost one.
+            if (trk) { seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk); round_done = true; }
+            stamp(7);
+            if (__builtin_expect((seedmask == 0) & (lit + nt > P.mqd) & (q_head < q_cnt), 1)) {
+                const int plen = __builtin_amdgcn_readlane(a_len, q_head);
+                if (__builtin_expect(plen > 0, 1)) {
+                    adv = __builtin_amdgcn_readlane(a_pos, q_head) - i;
+                    bpos = (int)((u32)__builtin_amdgcn_readlane((int)a_ref, q_head)); blen = plen;
+                    last_src = q_head++;
+                    return true;
+                }
+            }
+        } else scan_pos = i;
+        // everything else: refills, seed candidates to verify, candidates the lanes could not settle, the end of the query
+        int pos = i, guard = 0;
+        bool merge_done = false;
         for (;;) {
             if (refill_now) {                                        // (the one call site of refill: it is big)
                 if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
                 refill(pos);
                 refill_now = false;
             }
-            if (!round_done) {
-                // One round over the tracking steps: close seeds as in find_event_round, anchors from the queue.
-                round_done = true;
-                const int W = imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end);
-                u32 rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
-                u64 seedmask = 0;
-                if (W > 0) {
-                    const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
-                    qk = qkS[(u32)(i + lane)];
-                    rk0 = rkS[(u32)(r_end + w0)];
-                    rk1 = rkS[(u32)(r_end + w1)];
-                    qk = lane < nt ? qk : KM_INVALID;
-                    rk0 = lane < W ? rk0 : KM_INVALID;
-                    rk1 = lane + 64 < W ? rk1 : KM_INVALID;
-                    stamp(2);
-                    seedmask = __ballot(seed_prefilter(rk0, rk1, qk));
-                }
-                stamp(7);
-                // Common case (four rounds out of five of an unrelated pair): no tracking step has a close-seed
-                // candidate.  Then a tracking step can only hit through its anchor, which wins the arbitration
-                // unopposed unless it sits at reference position 0 (quirk Q1): the next event is simply the next
-                // queued candidate that passes this test (below), whether it is still a tracking step or a lost one.
-                if (__builtin_expect(seedmask != 0 || lit + nt <= P.mqd, 0)) {
+            if (!round_done) { seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk); round_done = true; }
+            if (!merge_done) {
+                merge_done = true;
+                if (seedmask != 0 || (trk && lit + nt <= P.mqd)) {
+                    // tracking steps with a seed candidate and / or a queued anchor, in step order
                     for (int it = 0; it < 130; ++it) {
                         const int ls = seedmask ? ctz64(seedmask) : 64;
                         int la = 64;
@@ -560,7 +577,7 @@ struct DevWave {
                             return true;
                         }
                     }
-                    if (lit + nt <= P.mqd) { adv = nt; return false; }   // mqd = 64: one more tracking step in the next call
+                    if (trk && lit + nt <= P.mqd) { adv = nt; return false; }   // mqd = 64: one more tracking step in the next call
                     pos = i + nt;
                 }
             }
