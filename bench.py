@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--collective", default="lzani", choices=("lzani", "torch"),
                     help="lzani: RCCL all-gather inside the engine library (lzani_comm_allgather); torch: torch.distributed nccl")
     ap.add_argument("--device", type=int, default=-1, help="force the HIP device ordinal")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the last slab (diagnostic builds that skip work on purpose)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,7 +257,7 @@ def main():
             out["cpu_baseline"]["parity_on_sample"] = "bit-exact" if np.array_equal(got, want) else "MISMATCH"
         else:
             out["cpu_baseline"] = None
-        if world == 1:
+        if world == 1 and not args.no_check:
             # pairs of the last timed slab, straight from the bench's own result buffer (dense-row form)
             import oracle as O
             res = shard.cpu().numpy().reshape(rows_max, n - 1, 3)
