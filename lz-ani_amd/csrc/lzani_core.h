@@ -528,10 +528,13 @@ LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q,
     }
     return rec;
 }
-// the backward extension over nb symbols is empty, by the record
-LZ_HD bool ext_rec_null_bwd(u32 rec, int nb, int aw)
+// the backward extension is empty, by the record; reach = how far back the machine may look, uncapped
+// (min(avail, i, bpos); the scan itself looks at min(64, reach) symbols, and aw <= 30 < 64)
+LZ_HD bool ext_rec_null_bwd(u32 rec, int reach, int aw)
 {
-    return (rec & (u32)lowmask(imin(nb, aw))) == 0 && (nb <= aw || (rec & EXT_REC_BRKB));
+    if (reach <= 0) return true;
+    const int m = imin(imin(reach, aw), 30);                    // 1 .. 30 (aw > 30: the record has every qual bit set)
+    return (rec & ((1u << m) - 1u)) == 0 && (reach <= aw || (rec & EXT_REC_BRKB));
 }
 
 // ---- the pair state machine ------------------------------------------------------------
@@ -731,7 +734,8 @@ struct PairMachine {
                 // move (a chance k-mer with random flanks: four extensions out of five of an unrelated pair).
                 u32 rec = EXT_REC_NONE;
                 const bool have_rec = !ALN && w.ext_record(rec);
-                const bool null_f = have_rec && (rec & EXT_REC_NULLF), null_b = nb == 0 || (have_rec && ext_rec_null_bwd(rec, nb, P.aw));
+                const bool null_f = have_rec && (rec & EXT_REC_NULLF);
+                const bool null_b = nb == 0 || (have_rec && ext_rec_null_bwd(rec, imin(avail, imin(i, bpos)), P.aw));
                 if (null_f & null_b) {
                     // the null event: no text access, no lane work; the match opens a region on its own
                     g.finalize();                                       // a match_distant factor follows
