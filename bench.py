@@ -123,8 +123,10 @@ def main():
     ap.add_argument("--lmin", type=int, default=36000, help="ancestor length range of the synthetic set")
     ap.add_argument("--lmax", type=int, default=44000)
     ap.add_argument("--params", default="", help="LZ parameter overrides, e.g. mal=15,msl=9,reg=60 (BASELINE configs[3])")
-    ap.add_argument("--collective", default="lzani", choices=("lzani", "torch"),
-                    help="lzani: RCCL all-gather inside the engine library (lzani_comm_allgather); torch: torch.distributed nccl")
+    ap.add_argument("--collective", default="lzani", choices=("lzani", "torch", "gloo"),
+                    help="lzani: RCCL all-gather inside the engine library (lzani_comm_allgather); torch: torch.distributed nccl; "
+                         "gloo: host-side all_gather -- only for rehearsing the N > 1 logic with several ranks on ONE GPU (--device 0), "
+                         "where RCCL refuses to run")
     ap.add_argument("--device", type=int, default=-1, help="force the HIP device ordinal")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the last slab (diagnostic builds that skip work on purpose)")
     args = ap.parse_args()
@@ -169,6 +171,7 @@ def main():
     per_rank = rows_max * (n - 1)                                 # padded shard, in results
     shard = torch.zeros(per_rank * 3, dtype=torch.int32, device="cuda")
     gathered = torch.zeros(world * per_rank * 3, dtype=torch.int32, device="cuda") if world > 1 else None
+    host_parts = [torch.zeros(per_rank * 3, dtype=torch.int32) for _ in range(world)] if args.collective == "gloo" else None
 
     def step(s):
         rows = SH.slab_rows(n, s, slab)
@@ -178,8 +181,11 @@ def main():
         if world > 1:
             if args.collective == "lzani":
                 eng.comm_allgather(shard.data_ptr(), gathered.data_ptr(), per_rank)
-            else:
+            elif args.collective == "torch":
                 dist.all_gather_into_tensor(gathered, shard)
+            else:
+                dist.all_gather(host_parts, shard.cpu())
+                gathered.copy_(torch.cat(host_parts))
         return rows, mine
 
     def fence():
@@ -218,6 +224,8 @@ def main():
         avg_launch_ms = kernel_ms / launches
         achieved = abytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         lay = eng.layout()
+        coll_name = {"lzani": "lzani_comm_allgather", "torch": "torch.distributed nccl",
+                     "gloo": "REHEARSAL: gloo through host memory, ranks may share a GPU"}[args.collective]
         out = {
             "metric": "genome-pairs/sec + achieved HBM GB/s, 10k×40kbp all2all at 1/2/4/8 GPUs",
             "value": value, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -231,7 +239,7 @@ def main():
                        "genomes": n, "seed": args.seed, "pairs_per_pass": n * (n - 1), "slab_rows": slab, "pairs_per_step": slab * (n - 1),
                        "pairs_timed": total_pairs, "pairs_timed_rank0": my_pairs,
                        "sharding": (f"rows of a slab dealt cyclically over {world} ranks (lzani_partition_rows), genomes replicated, one RCCL "
-                                    f"all-gather of int32[3] per pair per step ({'lzani_comm_allgather' if args.collective == 'lzani' else 'torch.distributed'})")
+                                    f"all-gather of int32[3] per pair per step ({coll_name})")
                                    if world > 1 else "single GPU, all rows",
                        "params": params,
                        "index_form": {"dir_bits": lay["dir_bits"], "tag_words": lay["tag_words"], "bucket_table": lay["bucket_table"],

@@ -175,3 +175,23 @@ def test_filtered_rows_lpt_gather_world2(tmp_path):
             assert tuple(got[e]) == tuple(full[r, x]), (k, r, x)
             e += 1
     assert e == len(q)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py's N > 1 logic on hardware: two ranks under torch.distributed.run share GPU 0 (RCCL refuses that, so the
+    all-gather goes through gloo), slabs dealt cyclically by lzani_partition_rows, every rank's HIP path, the gathered
+    slab checked against the oracle on rows of both ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--genomes", "240", "--seed", "9", "--slab", "50", "--lmin", "3000", "--lmax", "5000", "--collective", "gloo", "--device", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.split("\n") if ln.startswith("{")][0]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity_on_last_slab"] == "bit-exact"
+    assert d["config"]["pairs_timed"] == 3 * 50 * 239 and d["config"]["pairs_timed_rank0"] == 3 * 25 * 239
