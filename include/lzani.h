@@ -127,6 +127,8 @@ typedef struct lzani_layout_info {
     uint32_t batches_last_run;              /* batches of the last run                                               */
     uint64_t bytes_per_slot;                /* HBM bytes of one index slab                                           */
     uint64_t bytes_genomes;                 /* HBM bytes of packed texts + N masks + k-mer words                     */
+    int32_t  join_lists;                    /* 1: candidates come from a join with per-genome sorted k-mer lists (long genomes) */
+    int32_t  reserved;
 } lzani_layout_info;
 int lzani_get_layout(const lzani_ctx *ctx, lzani_layout_info *info);
 

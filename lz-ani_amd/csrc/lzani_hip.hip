@@ -22,6 +22,9 @@ __device__ int g_guard_trip = 0;   // see LZ_GUARD_TRIP in lzani_core.h
 __device__ unsigned long long g_stamp_acc[8];
 #endif
 
+int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_t n, int begin_bit, int end_bit,
+                    void* tmp, size_t* tmp_bytes, hipStream_t stream);      // lzani_sort.hip (hipCUB radix sort)
+
 #include "lzani_core.h"
 #include "lzani_layout.h"
 #include "lzani_kernels_index.h"
@@ -40,7 +43,7 @@ struct lzani_ctx {
     int n_cus = 256;
     std::string err;
 
-    u32 n = 0;
+    u32 n = 0, n_pending = 0;     // n_pending: genome count while lzani_set_genomes is still at work
     std::vector<int> L;
     std::vector<u64> nmoff;
     int Tmax = 0;
@@ -66,6 +69,16 @@ struct lzani_ctx {
     u64 tw_stride = 0;
     u32 slots = 0;
     u32 batches_last_run = 0;
+    // join form of candidate detection (long genomes): per-genome k-mer lists sorted by bucket
+    bool join_mode = false, join_ready = false;
+    unsigned long long* d_jkeys_in = nullptr;     // unsorted keys, koff[g] + p
+    unsigned long long* d_jkeys = nullptr;        // sorted
+    u64* d_jkoff = nullptr;                       // per genome: offset of its forward positions (n + 1)
+    u64* d_jsoff = nullptr;                       // per genome: offset of its sorted valid keys (n + 1)
+    u32* d_jcnt = nullptr;
+    void* d_jtmp = nullptr;
+    size_t jtmp_bytes = 0;
+    std::vector<u64> jkoff;
     u32 max_slots = 65535;        // gridDim.y limit; LZANI_MAX_SLOTS lowers it (tests force the multi-batch path)
     u64 dir_stride = 0, ent_stride = 0;
     unsigned long long* d_cursor = nullptr;
@@ -115,6 +128,9 @@ int fail(lzani_ctx* c, int code, const std::string& msg)
 void free_genomes(lzani_ctx* c)
 {
     hipFree(c->d_t2); hipFree(c->d_nm); hipFree(c->d_nmoff); hipFree(c->d_L); hipFree(c->d_kmL); hipFree(c->d_kmS); hipFree(c->d_hasN);
+    hipFree(c->d_jkeys_in); hipFree(c->d_jkeys); hipFree(c->d_jkoff); hipFree(c->d_jsoff); hipFree(c->d_jcnt); hipFree(c->d_jtmp);
+    c->d_jkeys_in = c->d_jkeys = nullptr; c->d_jkoff = c->d_jsoff = nullptr; c->d_jcnt = nullptr; c->d_jtmp = nullptr; c->jtmp_bytes = 0;
+    c->join_mode = c->join_ready = false;
     c->d_hasN = nullptr;
     c->d_t2 = c->d_nm = c->d_nmoff = nullptr; c->d_L = nullptr; c->d_kmL = c->d_kmS = nullptr; c->kmers_ready = false;
     c->n = 0;
@@ -140,6 +156,17 @@ void choose_index_form(lzani_ctx* c)
                        ? ((u64)4 << c->geo.dirbits) : 0;
     const char* t = getenv("LZANI_NO_TAGWORDS");
     c->tw_stride = (c->bk_stride && tagbits <= 7 && !(t && *t == '1')) ? ((u64)1 << c->geo.dirbits) : 0;
+    // Join form of candidate detection: where the tag words of one reference exceed what an L2 holds by far, a random
+    // probe per query position costs one HBM line each; the query's k-mer list sorted by bucket turns the probes into
+    // two streams (DevWave::join).  Needs the anchor queue (tag words, seed window <= 128) and keys of 64 bits.
+    {
+        const char* nj = getenv("LZANI_NO_JOIN");
+        const char* jm = getenv("LZANI_JOIN_MIN_BYTES");
+        const u64 min_bytes = jm ? strtoull(jm, nullptr, 10) : (8ull << 20);
+        const int gbits = ceil_log2((u64)std::max<u32>(c->n_pending, 2));
+        c->join_mode = c->tw_stride && c->tw_stride * 4 >= min_bytes && c->P.mqd + c->P.mrd <= 128 &&
+                       gbits + c->geo.kb + c->geo.posbits <= 64 && !(nj && *nj == '1');
+    }
     const char* ms = getenv("LZANI_MAX_SLOTS");
     c->max_slots = ms && atoi(ms) > 0 ? (u32)std::min(65535, atoi(ms)) : 65535u;
 }
@@ -165,6 +192,70 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
 
 GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmoff, c->d_L, c->d_kmL, c->d_kmS, c->d_hasN}; }
 
+// Join form: the k-mer list of every genome as a query, sorted by (genome, bucket) -- k_join_keys + hipCUB radix sort,
+// once per run, behind k_kmers (it is part of the path's work like the k-mer words it is made from).
+int build_join_lists(lzani_ctx* c)
+{
+    const u32 n = c->n;
+    if (!c->d_jkoff) {
+        c->jkoff.assign((size_t)n + 1, 0);
+        for (u32 g = 0; g < n; ++g) c->jkoff[g + 1] = c->jkoff[g] + (u64)c->L[g];
+        HIPCHK(c, hipMalloc(&c->d_jkoff, ((size_t)n + 1) * 8));
+        HIPCHK(c, hipMalloc(&c->d_jsoff, ((size_t)n + 1) * 8));
+        HIPCHK(c, hipMalloc(&c->d_jcnt, (size_t)n * 4));
+        HIPCHK(c, hipMalloc(&c->d_jkeys_in, std::max<u64>(c->jkoff[n], 1) * 8));
+        HIPCHK(c, hipMalloc(&c->d_jkeys, std::max<u64>(c->jkoff[n], 1) * 8));
+        HIPCHK(c, hipMemcpyAsync(c->d_jkoff, c->jkoff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    int Lmax = 0;
+    for (u32 g = 0; g < n; ++g) Lmax = std::max(Lmax, c->L[g]);
+    const int shift_g = c->geo.kb + c->geo.posbits, gbits = ceil_log2((u64)std::max<u32>(n, 2));
+    HIPCHK(c, hipMemsetAsync(c->d_jcnt, 0, (size_t)n * 4, c->stream));
+    for (u32 g0 = 0; g0 < n && Lmax > 0; g0 += 32768) {
+        const u32 cnt = std::min<u32>(32768, n - g0);
+        GenomeTab G = gtab(c);
+        G.nmoff += g0; G.L += g0;
+        // (the genome number of the key is global: the kernel adds g0 through the offset tables it is given)
+        hipLaunchKernelGGL(k_join_keys, dim3((Lmax + 255) / 256, cnt), dim3(256), 0, c->stream, G, c->d_jkoff + g0, c->d_jkeys_in,
+                           c->d_jcnt + g0, shift_g, c->geo.posbits, Lmax, g0);
+    }
+    HIPCHK(c, hipGetLastError());
+    std::vector<u32> valid(n);
+    HIPCHK(c, hipMemcpyAsync(valid.data(), c->d_jcnt, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // sort in groups of whole genomes below 2^30 keys; invalid keys (all ones) end up behind the group's valid ones
+    std::vector<u64> soff((size_t)n + 1, 0);
+    for (u32 g0 = 0; g0 < n;) {
+        u32 g1 = g0;
+        u64 keys = 0;
+        while (g1 < n && (g1 == g0 || keys + (u64)c->L[g1] <= (1ull << 30))) keys += (u64)c->L[g1++];
+        if (keys > 0x7FFFFFF0ull) return fail(c, LZANI_ERR_ARG, "join lists: a genome of more than 2^31 positions");
+        u64 at = c->jkoff[g0];
+        for (u32 g = g0; g < g1; ++g) { soff[g] = at; at += valid[g]; }
+        if (g1 == n) soff[n] = at;
+        if (keys) {
+            size_t need = 0;
+            int e = lzani_sort_keys(c->d_jkeys_in + c->jkoff[g0], c->d_jkeys + c->jkoff[g0], keys, c->geo.posbits, shift_g + gbits, nullptr, &need, c->stream);
+            if (e != 0) return fail(c, LZANI_ERR_DEVICE, "join lists: radix sort (size query) failed");
+            if (need > c->jtmp_bytes) {
+                hipFree(c->d_jtmp); c->d_jtmp = nullptr; c->jtmp_bytes = 0;
+                HIPCHK(c, hipMalloc(&c->d_jtmp, need));
+                c->jtmp_bytes = need;
+            }
+            need = c->jtmp_bytes;
+            e = lzani_sort_keys(c->d_jkeys_in + c->jkoff[g0], c->d_jkeys + c->jkoff[g0], keys, c->geo.posbits, shift_g + gbits, c->d_jtmp, &need, c->stream);
+            if (e != 0) return fail(c, LZANI_ERR_DEVICE, "join lists: radix sort failed");
+        }
+        g0 = g1;
+    }
+    // (a genome's list ends after its valid keys -- d_jcnt -- not where the next list begins: between two groups sit the
+    // invalid keys of the first)
+    HIPCHK(c, hipMemcpyAsync(c->d_jsoff, soff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tm.index_launches += 2;
+    return LZANI_OK;
+}
+
 // Index build of `rows` references (device list d_ref_ids) into slots 0..rows-1.
 int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
 {
@@ -185,6 +276,7 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
         }
         c->kmers_ready = true;
         c->tm.index_launches += 1;
+        if (c->join_mode) { int rc = build_join_lists(c); if (rc) return rc; }
     }
     const char* nolds = getenv("LZANI_NO_LDS_INDEX");
     const char* ldsmax = getenv("LZANI_LDS_INDEX_MAX_DIRBITS");
@@ -312,6 +404,14 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     const Params& q = c->P;
     const bool defp = q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3;
     std::vector<char> launched(n_batches, 0);
+    DevBuf<unsigned long long> d_cbits;                      // join form: one candidate bitmap per resident wave
+    u64 cbits_stride = 0;
+    if (c->join_mode && !rs) {
+        int Lmax = 0;
+        for (u32 g = 0; g < c->n; ++g) Lmax = std::max(Lmax, c->L[g]);
+        cbits_stride = (u64)((Lmax + c->P.mrd) >> 6) + 8;
+        HIPCHK(c, d_cbits.alloc((size_t)max_blocks * 4 * cbits_stride));
+    }
 
     for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += c->slots) {
         const u32 rows = std::min(c->slots, n_rows - k0);
@@ -334,19 +434,27 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.out = d_out; pa.cursor = c->d_cursor;
             pa.qorder = d_qorder + k0; pa.qcum = d_qcum + k0 + b;
             for (int x = 0; x <= NQUEUES; ++x) pa.qb[x] = qb[(size_t)b * (NQUEUES + 1) + x];
+            pa.skeys = cbits_stride ? c->d_jkeys : nullptr; pa.soff = c->d_jsoff; pa.scnt = c->d_jcnt;
+            pa.cbits = d_cbits.p; pa.cbits_stride = cbits_stride;
             pa.reg_out = rs ? rs->d_regions : nullptr; pa.reg_count = rs ? rs->d_count : nullptr; pa.reg_cap = rs ? rs->capacity : 0;
             HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, NQUEUES * sizeof(unsigned long long), c->stream));
             const u64 waves = e1 - e0;
             const dim3 gd((u32)std::min<u64>((waves + 3) / 4, max_blocks)), bd(256);
             HIPCHK(c, hipEventRecord(ev[2], c->stream));
 #define LZ_PAIRS(F, N, D, A, B) hipLaunchKernelGGL((k_pairs<F, N, D, A, B>), gd, bd, 0, c->stream, pa)
+#define LZ_PAIRS_JOIN(N, D) hipLaunchKernelGGL((k_pairs<true, N, D, false, true, true>), gd, bd, 0, c->stream, pa)
             const bool fast = c->d_kmL != nullptr, tw = pa.tw != nullptr, nf = c->all_nfree;
             if (rs) {                                   // alignment output: one generic instantiation per index form
                 if (!fast) LZ_PAIRS(false, false, false, true, false);
                 else if (tw) LZ_PAIRS(true, false, false, true, true);
                 else LZ_PAIRS(true, false, false, true, false);
             } else if (!fast) LZ_PAIRS(false, false, false, false, false);
-            else if (tw) {
+            else if (tw && pa.skeys) {                  // long genomes: candidates by the join
+                if (nf && defp) LZ_PAIRS_JOIN(true, true);
+                else if (nf) LZ_PAIRS_JOIN(true, false);
+                else if (defp) LZ_PAIRS_JOIN(false, true);
+                else LZ_PAIRS_JOIN(false, false);
+            } else if (tw) {
                 if (nf && defp) LZ_PAIRS(true, true, true, false, true);
                 else if (nf) LZ_PAIRS(true, true, false, false, true);
                 else if (defp) LZ_PAIRS(true, false, true, false, true);
@@ -357,6 +465,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (defp) LZ_PAIRS(true, false, true, false, false);
                 else LZ_PAIRS(true, false, false, false, false);
             }
+#undef LZ_PAIRS_JOIN
 #undef LZ_PAIRS
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(ev[3], c->stream));
@@ -494,6 +603,7 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
         HIPCHK(c, hipMalloc(&c->d_kmL, total_nm * 64 * 4));
         HIPCHK(c, hipMalloc(&c->d_kmS, total_nm * 64 * 4));
     }
+    c->n_pending = n;
     choose_index_form(c);
     // The caller's sequences are separate host buffers: they go up through two pinned 64 MB staging buffers, the
     // copy of one overlapping the fill of the other (the 4 GB of config 5 take as long as the PCIe link needs).
@@ -623,6 +733,7 @@ int lzani_get_layout(const lzani_ctx* c, lzani_layout_info* o)
     o->slots = c->slots; o->batches_last_run = c->batches_last_run;
     o->bytes_per_slot = 4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride);
     o->bytes_genomes = c->total_nm * (16 + 8) + (c->d_kmL ? c->total_nm * 64 * 8 : 0);
+    o->join_lists = c->join_mode; o->reserved = 0;
     return LZANI_OK;
 }
 

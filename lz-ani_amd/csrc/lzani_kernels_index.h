@@ -43,6 +43,29 @@ __global__ void k_kmers(GenomeTab G, u32* __restrict__ kmL, u32* __restrict__ km
     kmS[64 * o + p] = b;
 }
 
+// k_join_keys: the k-mer list of every genome AS A QUERY, one 64-bit key per forward position with a mal-mer:
+//   key = genome << (kb + posbits) | mixed mal-mer hash << posbits | position
+// (invalid positions get all ones and sort behind everything).  Sorted by genome and hash (lzani_sort_keys), genome g's
+// keys are contiguous and ascend in bucket: a pair then finds its candidates by a JOIN of the query's sorted list with
+// the reference's tag words -- both streamed in bucket order -- instead of one random probe per query position
+// (DevWave::join).  Long genomes only: a 64 MB tag-word table answers random probes at one HBM line per probe.
+__global__ void k_join_keys(GenomeTab G, const u64* __restrict__ koff, unsigned long long* __restrict__ keys,
+                            u32* __restrict__ valid_cnt, int shift_g, int posbits, int Lmax, u32 g_base)
+{
+    const u32 g = blockIdx.y;                    // index into the (offset) tables; the key carries g_base + g
+    const int L = G.L[g];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Lmax) return;
+    bool ok = false;
+    if (p < L) {
+        const u32 h = G.kmL[64 * G.nmoff[g] + p];
+        ok = h != KM_INVALID;
+        keys[koff[g] + p] = ok ? ((unsigned long long)(g_base + g) << shift_g) | ((unsigned long long)h << posbits) | (unsigned long long)p : ~0ULL;
+    }
+    const u64 b = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&valid_cnt[g], (u32)__popcll(b));
+}
+
 // ------------------------------------------------------------------------------------------
 // k_pack: one thread per 64-symbol block of a reference text.
 // ------------------------------------------------------------------------------------------

@@ -19,8 +19,9 @@ enum { AQ_CAP = 64, AQ_MAXCHUNKS = 32, AQ_LANE_CAP = 32, AQ_LDS_CAND = 128, SEED
 enum : u32 { AQ_COMPLEX = 0x80000000u, AQ_LONG = 0x40000000u, AQ_POS = 0x3FFFFFFFu };
 enum { AQ_NONE = 0x7FFFFFFF };
 
-// FAST: per-position k-mer words exist;  BK: the bucket table and its tag words exist
-template <bool FAST, bool BK = false>
+// FAST: per-position k-mer words exist;  BK: the bucket table and its tag words exist;  JOIN: the candidates of a pair
+// come from a join with the query's sorted k-mer list (long genomes) instead of a probe per query position
+template <bool FAST, bool BK = false, bool JOIN = false>
 struct DevWave {
     const Params& P;
     TextView R, Q;
@@ -41,6 +42,9 @@ struct DevWave {
     int scan_pos = 0, q_head = 0, q_cnt = 0;
     int last_src = -1;   // queue entry the event just returned came from, if its null-extension record applies
     u32 a_ext = EXT_REC_NONE;    // lane k: null-extension record of candidate k (lzani_core.h: null_ext_record)
+    // Join form of candidate detection (long genomes): the wave's candidate bitmap over the query positions of the
+    // pair, filled by join() before the scan; nullptr = candidates are probed position by position (refill)
+    unsigned long long* cand_bits = nullptr;
     int a_pos = AQ_NONE, a_len = 0;
     u32 a_ref = 0;
     __device__ __forceinline__ void emit_region(const RegionCoords& c) const
@@ -373,7 +377,24 @@ struct DevWave {
         // Four chunks of 64 positions per turn: their k-mer words are requested together, then their tag words (two
         // memory round trips per 256 positions instead of eight), then the candidates are compacted chunk by chunk.
         // A turn may look beyond iend or find more than the queue takes: the surplus is masked / detected again.
-        for (int turn = 0; turn < AQ_MAXCHUNKS / 4 && scan_pos < iend && ncand < AQ_CAP; ++turn) {
+        for (int turn = 0; JOIN && turn < AQ_MAXCHUNKS / 4 && scan_pos < iend && ncand < AQ_CAP; ++turn) {
+            // join form: the candidates of 64 positions are one (unaligned) word of the pair's bitmap
+            const u32 w0 = (u32)scan_pos >> 6;
+            const int sh = scan_pos & 63;
+            const unsigned long long wd = cand_bits[w0 + (u32)imin(lane, 4)];        // lanes 0..4: the five words of this turn
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (scan_pos >= iend || ncand >= AQ_CAP) break;               // wave-uniform
+                const u64 bal = ((bcast64(wd, c) >> sh) | ((bcast64(wd, c + 1) << 1) << (63 - sh))) & lowmask(iend - scan_pos);
+                if (bal) {
+                    const int at = ncand + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                    if ((bal >> lane) & 1ULL) cq[at] = (u32)(scan_pos + lane);
+                    ncand += popc64(bal);
+                }
+                scan_pos = imin(scan_pos + 64, iend);
+            }
+        }
+        for (int turn = 0; !JOIN && turn < AQ_MAXCHUNKS / 4 && scan_pos < iend && ncand < AQ_CAP; ++turn) {
             u32 hq[4], w[4];
             bool valid[4];
 #pragma unroll
@@ -414,8 +435,17 @@ struct DevWave {
         // resolve: lane k owns candidate k
         const bool live = lane < q_cnt;
         const int qp = live ? (int)cq[lane] : 0;
-        const u32 slot = live ? cq[AQ_LDS_CAND + lane] : (u32)AQ_COMPLEX;
+        u32 slot = live ? cq[AQ_LDS_CAND + lane] : (u32)AQ_COMPLEX;
         lds_order();
+        if (JOIN) {                                        // join form: the bitmap says where, not which bucket slot
+            const u32 hq = qkL[(u32)qp];
+            const bool ok = live & (hq != KM_INVALID);
+            const u32 w = I.tw[ok ? hq >> tb : 0u];
+            const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);
+            const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
+            const bool cplx = (w == TW_OVERFLOW) | ((z & (z - 1)) != 0) | (z == 0);
+            slot = (!ok | cplx) ? (u32)AQ_COMPLEX : 4u * (hq >> tb) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
+        }
         const bool simple = !(slot & AQ_COMPLEX);
         // (a lane without a simple candidate must not wander: slot 0 may hold BK_EMPTY, whose position bits point
         // far beyond the text)
@@ -628,6 +658,39 @@ struct DevWave {
     }
 };
 
+// The candidates of a whole pair by a JOIN (long genomes; k_join_keys).  The query's k-mer list is sorted by bucket, so
+// the 64 lanes of a step read 64 consecutive keys and probe tag words that lie within a few hundred buckets of each
+// other: a handful of consecutive 128-byte lines per step, each line of the reference's table fetched once per pair,
+// against one line per query position for the probe form (5 Mbp: 81 G random probes per launch = 5.5 TB/s of line
+// fetches, the whole cost of the step).  A hit sets the position's bit in the wave's candidate bitmap.  Runs before
+// anything else of the pair is set up, so that its registers are its own.
+__device__ __forceinline__ void join_candidates(const u32* __restrict__ tw, int kb, int dirbits, int posbits, u32 tagmask,
+                                                const unsigned long long* __restrict__ keys, u32 n_keys,
+                                                unsigned long long* __restrict__ cand_bits, int words, int lane)
+{
+    for (int k = lane; k < words; k += 64) cand_bits[k] = 0;
+    const int tb = kb - dirbits;
+    const u32 hmask = (u32)lowmask(kb), pmask = (u32)lowmask(posbits);
+    u32* const bits32 = reinterpret_cast<u32*>(cand_bits);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // the zeroes before the atomics of this wave
+    for (u32 k0 = 0; k0 < n_keys; k0 += 128) {
+        unsigned long long e[2];
+        u32 w[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { const u32 k = k0 + 64 * c + lane; e[c] = keys[k < n_keys ? k : n_keys - 1]; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) w[c] = tw[(((u32)(e[c] >> posbits)) & hmask) >> tb];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const u32 hq = ((u32)(e[c] >> posbits)) & hmask, pos = (u32)e[c] & pmask;
+            const u32 x = w[c] ^ ((0x80u | (hq & tagmask)) * 0x01010101u);
+            const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
+            if ((k0 + 64 * c + lane < n_keys) & ((z != 0) | (w[c] == TW_OVERFLOW))) atomicOr(&bits32[pos >> 5], 1u << (pos & 31));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");                 // the bits before the scan reads them
+}
+
 struct PairArgs {
     GenomeTab G;
     Params P;
@@ -651,6 +714,13 @@ struct PairArgs {
     const u64* qcum;
     u32 qb[NQUEUES + 1];
     unsigned long long* cursor;   // NQUEUES tickets counters
+    // join form of candidate detection (long genomes; nullptr = probe form): per-genome k-mer lists sorted by bucket
+    // (keys of genome g: skeys[soff[g] .. soff[g+1])) and one candidate bitmap of cbits_stride words per wave
+    const unsigned long long* skeys;
+    const u64* soff;                 // begin of genome g's sorted keys
+    const u32* scnt;                 // their number
+    unsigned long long* cbits;
+    u64 cbits_stride;
     lzani_region* reg_out;        // alignment instantiation only
     unsigned long long* reg_count;
     unsigned long long reg_cap;
@@ -667,7 +737,8 @@ __device__ __forceinline__ u32 xcc_id()
 // context holds an N (the N mask is never consulted); DEFP = the LZ parameters are the reference's
 // defaults (params.h:34-48), folded into the code as constants.
 // ALN = also emit the regions of every pair (--out-alignment).
-template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false>
+// JOIN = candidates by a join with sorted k-mer lists (long genomes; needs FAST and BK).
+template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false, bool JOIN = false>
 __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 {
     const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
@@ -703,6 +774,12 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         const u64 e = a.row_off[slot] + j;
         const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
 
+        unsigned long long* cand_bits = nullptr;
+        if (JOIN) {
+            cand_bits = a.cbits + (u64)(blockIdx.x * 4 + (threadIdx.x >> 6)) * a.cbits_stride;
+            join_candidates(a.tw + slot * a.tw_stride, a.geo.kb, a.geo.dirbits, a.geo.posbits, a.geo.tagmask,
+                            a.skeys + a.soff[q], a.scnt[q], cand_bits, ((a.G.L[q] + (DEFP ? 40 : a.P.mrd)) >> 6) + 8, lane);
+        }
         const int Lr = a.G.L[r], Lq = a.G.L[q];
         const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
         const int T = ref_text_len(Lr, Pk.mrd), D = Lq + Pk.mrd;
@@ -713,13 +790,14 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
         iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
         const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
-        DevWave<FAST, BK> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
+        DevWave<FAST, BK, JOIN> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                         qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
                         lds,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
                         FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
         w.iend = D - Pk.msl;
-        PairMachine<DevWave<FAST, BK>, ALN> m(w, Pk, T, D);
+        w.cand_bits = cand_bits;
+        PairMachine<DevWave<FAST, BK, JOIN>, ALN> m(w, Pk, T, D);
         int res[3];
 #ifdef LZANI_STAMPS
         for (int k = 0; k < 8; ++k) w.acc[k] = 0;

@@ -46,17 +46,17 @@ class LayoutInfo(C.Structure):
     _fields_ = [("key_bits", C.c_int32), ("dir_bits", C.c_int32), ("pos_bits", C.c_int32), ("tag_mask", C.c_uint32),
                 ("kmer_words", C.c_int32), ("bucket_table", C.c_int32), ("tag_words", C.c_int32), ("n_free", C.c_int32),
                 ("slots", C.c_uint32), ("batches_last_run", C.c_uint32), ("bytes_per_slot", C.c_uint64),
-                ("bytes_genomes", C.c_uint64)]
+                ("bytes_genomes", C.c_uint64), ("join_lists", C.c_int32), ("reserved", C.c_int32)]
 
 
 def build_library(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     deps = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("lzani_core.h", "lzani_layout.h", "lzani_kernels_index.h",
-                                                             "lzani_kernels_pairs.h", "lzani_multi.h")] + [os.path.join(ROOT, "include", "lzani.h")]
+                                                             "lzani_kernels_pairs.h", "lzani_multi.h", "lzani_sort.hip")] + [os.path.join(ROOT, "include", "lzani.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wno-unused-value", "-o", LIB_PATH, SRC, "-lrccl"]
+           "-Wno-unused-value", "-o", LIB_PATH, SRC, os.path.join(HERE, "csrc", "lzani_sort.hip"), "-lrccl"]
     subprocess.check_call(cmd)
     return LIB_PATH
 

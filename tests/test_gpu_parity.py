@@ -513,7 +513,7 @@ def test_bacterial_geometry_5mbp():
     eng.set_genomes(seqs)
     lay = eng.layout()
     assert (lay["key_bits"], lay["dir_bits"], lay["pos_bits"], lay["tag_mask"]) == (30, 24, 24, 0x3F)
-    assert lay["kmer_words"] == 1 and lay["bucket_table"] == 1 and lay["tag_words"] == 1
+    assert lay["kmer_words"] == 1 and lay["bucket_table"] == 1 and lay["tag_words"] == 1 and lay["join_lists"] == 1
     got = eng.all2all()
     assert eng.layout()["bytes_per_slot"] > 400 << 20
     eng.close()
@@ -521,6 +521,48 @@ def test_bacterial_geometry_5mbp():
     bad = np.argwhere((got != want).any(axis=2))
     assert len(bad) == 0, (bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
     assert got[0, 1, 0] > 4_500_000 and got[3, 4, 0] > 4_000_000 and got[0, 3, 0] < 1_000_000
+
+
+def test_join_form_of_candidate_detection(monkeypatch):
+    """Long genomes find their candidates by a join of the query's sorted k-mer list with the reference's tag words
+    instead of one probe per query position.  LZANI_JOIN_MIN_BYTES=1 turns the join on at every size, so the committed
+    reference vectors, a seeded fuzz (N runs, inversions, random parameters), a multi-batch run and the filtered row
+    form all go through it; results must not change."""
+    monkeypatch.setenv("LZANI_JOIN_MIN_BYTES", "1")
+    with open(os.path.join(U.GOLD, "ref_vectors.json")) as f:
+        vec = json.load(f)
+    done = 0
+    for key, item in vec["sets"].items():
+        if not key.startswith("synth24"):
+            continue
+        eng = L.Engine(item["params"])
+        eng.set_genomes(_inputs("synth24"))
+        join = eng.layout()["join_lists"]
+        got = eng.all2all()
+        eng.close()
+        assert np.array_equal(got, np.array(item["res"], dtype=np.int32)), key
+        done += join
+    assert done >= 8                                   # the join really ran (where tag words and the anchor queue apply)
+    st = SG.Stream(9001)
+    for it in range(40):
+        prm, seqs = U.fuzz_case_medium(st)
+        assert np.array_equal(gpu_all2all(seqs, prm), O.oracle_all2all(seqs, prm, threads=16)), (it, prm)
+    monkeypatch.setenv("LZANI_MAX_SLOTS", "4")
+    _, seqs = SG.make_set(14, 21, lmin=9000, lmax=16000, fam=7)
+    seqs[5] = np.concatenate([seqs[5][:3000], np.full(33, 5, np.uint8), seqs[5][3000:]])
+    want = O.oracle_all2all(seqs, None, threads=16)
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    assert eng.layout()["join_lists"] == 1
+    assert np.array_equal(eng.all2all(), want) and eng.layout()["batches_last_run"] == 4
+    rr, off, q = [3, 3, 9, 0], [0, 5, 5, 11, 13], [1, 2, 4, 5, 13, 0, 1, 2, 3, 4, 5, 7, 9]
+    flat = eng.run_rows(rr, off, q)
+    eng.close()
+    e = 0
+    for row, r in enumerate(rr):
+        for x in q[off[row]:off[row + 1]]:
+            assert flat[e].tolist() == want[r, x].tolist(), (row, r, x)
+            e += 1
 
 
 def test_device_group_single_process(monkeypatch):
