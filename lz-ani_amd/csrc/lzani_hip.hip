@@ -216,7 +216,7 @@ int build_join_lists(lzani_ctx* c)
         GenomeTab G = gtab(c);
         G.nmoff += g0; G.L += g0;
         // (the genome number of the key is global: the kernel adds g0 through the offset tables it is given)
-        hipLaunchKernelGGL(k_join_keys, dim3((Lmax + 255) / 256, cnt), dim3(256), 0, c->stream, G, c->d_jkoff + g0, c->d_jkeys_in,
+        hipLaunchKernelGGL(k_join_keys, dim3((Lmax + 4095) / 4096, cnt), dim3(256), 0, c->stream, G, c->d_jkoff + g0, c->d_jkeys_in,
                            c->d_jcnt + g0, shift_g, c->geo.posbits, Lmax, g0);
     }
     HIPCHK(c, hipGetLastError());

@@ -49,21 +49,31 @@ __global__ void k_kmers(GenomeTab G, u32* __restrict__ kmL, u32* __restrict__ km
 // keys are contiguous and ascend in bucket: a pair then finds its candidates by a JOIN of the query's sorted list with
 // the reference's tag words -- both streamed in bucket order -- instead of one random probe per query position
 // (DevWave::join).  Long genomes only: a 64 MB tag-word table answers random probes at one HBM line per probe.
-__global__ void k_join_keys(GenomeTab G, const u64* __restrict__ koff, unsigned long long* __restrict__ keys,
-                            u32* __restrict__ valid_cnt, int shift_g, int posbits, int Lmax, u32 g_base)
+__global__ void __launch_bounds__(256) k_join_keys(GenomeTab G, const u64* __restrict__ koff, unsigned long long* __restrict__ keys,
+                                                   u32* __restrict__ valid_cnt, int shift_g, int posbits, int Lmax, u32 g_base)
 {
+    enum { PER_THREAD = 16 };                    // positions per thread: one atomic per block of 4,096 positions
+    __shared__ u32 s_cnt;
     const u32 g = blockIdx.y;                    // index into the (offset) tables; the key carries g_base + g
     const int L = G.L[g];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= Lmax) return;
-    bool ok = false;
-    if (p < L) {
-        const u32 h = G.kmL[64 * G.nmoff[g] + p];
-        ok = h != KM_INVALID;
-        keys[koff[g] + p] = ok ? ((unsigned long long)(g_base + g) << shift_g) | ((unsigned long long)h << posbits) | (unsigned long long)p : ~0ULL;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const u32* km = G.kmL + 64 * G.nmoff[g];
+    unsigned long long* out = keys + koff[g];
+    u32 mine = 0;
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int p = (blockIdx.x * PER_THREAD + k) * 256 + threadIdx.x;
+        if (p >= L) break;
+        const u32 h = km[p];
+        const bool ok = h != KM_INVALID;
+        out[p] = ok ? ((unsigned long long)(g_base + g) << shift_g) | ((unsigned long long)h << posbits) | (unsigned long long)p : ~0ULL;
+        mine += ok;
     }
-    const u64 b = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&valid_cnt[g], (u32)__popcll(b));
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&valid_cnt[g], s_cnt);
+    (void)Lmax;
 }
 
 // ------------------------------------------------------------------------------------------
