@@ -49,8 +49,19 @@ struct DevWave {
     u32 a_ref = 0;
     __device__ __forceinline__ void emit_region(const RegionCoords& c) const
     {
-        // one slot per wave without a lane-dependent branch (see the note at the ticket fetch)
-        const unsigned long long old = atomicAdd(reg_count, lane == 0 ? 1ULL : 0ULL);
+        // One slot per wave, reserved by ONE lane and without a lane-dependent branch (see the note at the ticket fetch:
+        // a second `if (lane == 0)` inside the persistent loop let the compiler split lane 0 from the rest): the exec
+        // mask is narrowed to lane 0 around the returning atomic by hand, 63 no-op atomics on one address less per region.
+        unsigned long long old, saved;
+        const unsigned long long one = 1ULL;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "global_atomic_add_x2 %[old], %[addr], %[one], off sc0\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [old] "=&v"(old), [sv] "=&s"(saved)
+                     : [addr] "v"(reg_count), [one] "v"(one)
+                     : "memory");
         const u32 lo = __builtin_amdgcn_readfirstlane((u32)old), hi = __builtin_amdgcn_readfirstlane((u32)(old >> 32));
         const unsigned long long slot = ((unsigned long long)hi << 32) | lo;
         if (slot < reg_cap) {
@@ -807,7 +818,7 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         m.run(res);
 #ifdef LZANI_STAMPS
         w.stamp(0);
-        if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_stamp_acc[k], w.acc[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_stamp_acc[k], lane == 0 ? w.acc[k] : 0ULL);      // (no lane-dependent branch in this loop)
 #endif
         int* o = a.out + 3 * e;          // every lane stores the same wave-uniform values
         o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
