@@ -815,6 +815,10 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         w.cur = 0;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.t0) :: "memory");
 #endif
+#if defined(LZANI_EXP) && LZANI_EXP == 3                      // diagnostic build: the join alone, no scan
+        res[0] = res[1] = res[2] = 0;
+        if (!JOIN)
+#endif
         m.run(res);
 #ifdef LZANI_STAMPS
         w.stamp(0);
