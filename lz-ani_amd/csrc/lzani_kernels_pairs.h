@@ -526,6 +526,25 @@ struct DevWave {
         if (__builtin_expect(al < P.mal, 0)) { ap = 0; al = 0; }
     }
 
+    // which of the steps [i, i + nt), nt <= 64, are candidates (have an anchor): the detect of refill for one chunk, nothing
+    // resolved.  For tracking rounds the queue does not cover -- the scan has jumped over it, i.e. an extension moved: a
+    // related stretch, where every position is a candidate and resolving 64 of them per event would be wasted.
+    __device__ __forceinline__ u64 detect_steps(int i, int nt) const
+    {
+        if (JOIN) {
+            const int sh = i & 63;
+            const unsigned long long wd = cand_bits[((u32)i >> 6) + (u32)imin(lane, 1)];
+            return ((bcast64(wd, 0) >> sh) | ((bcast64(wd, 1) << 1) << (63 - sh))) & lowmask(nt);
+        }
+        const int tb = I.kb - I.dirbits;
+        const u32 hq = qkL[(u32)(i + lane)];
+        const bool valid = (lane < nt) & (hq != KM_INVALID);
+        const u32 w = I.tw[valid ? hq >> tb : 0u];
+        const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);
+        const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
+        return __ballot(valid & ((z != 0) | (w == TW_OVERFLOW)));
+    }
+
     // the close-seed probe of the tracking steps [i, i + nt): which steps have a candidate in their window
     __device__ __forceinline__ u64 track_round(int i, int nt, int r_end, int lit, u32& rk0, u32& rk1, u32& qk) const
     {
@@ -572,10 +591,15 @@ struct DevWave {
                     return true;
                 }
             }
-        } else scan_pos = i;
+        }
         // everything else: refills, seed candidates to verify, candidates the lanes could not settle, the end of the query
         int pos = i, guard = 0;
         bool merge_done = false;
+        // A tracking round the queue does not cover runs LIGHT: its anchors are detected for the tracking steps alone
+        // and verified by the wave one at a time, only at the steps the round really reaches (as find_event_round does).
+        const bool light = trk & refill_now;
+        u64 lightmask = 0;
+        if (light) { lightmask = detect_steps(i, nt); refill_now = false; }
         for (;;) {
             if (refill_now) {                                        // (the one call site of refill: it is big)
                 if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
@@ -585,18 +609,24 @@ struct DevWave {
             if (!round_done) { seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk); round_done = true; }
             if (!merge_done) {
                 merge_done = true;
-                if (seedmask != 0 || (trk && lit + nt <= P.mqd)) {
-                    // tracking steps with a seed candidate and / or a queued anchor, in step order
+                if (seedmask != 0 || (trk && lit + nt <= P.mqd) || light) {
+                    // tracking steps with a seed candidate and / or an anchor (queued, or detected just now), in step order
                     for (int it = 0; it < 130; ++it) {
                         const int ls = seedmask ? ctz64(seedmask) : 64;
                         int la = 64;
-                        if (q_head < q_cnt) la = imin(64, __builtin_amdgcn_readlane(a_pos, q_head) - i);
+                        if (light) { if (lightmask) la = ctz64(lightmask); }
+                        else if (q_head < q_cnt) la = imin(64, __builtin_amdgcn_readlane(a_pos, q_head) - i);
                         if (la >= nt) la = 64;
                         const int l = imin(ls, la);
                         if (l >= 64) break;
                         const int qp = i + l;
                         int ap = 0, al = 0, src = -1;
-                        if (la == l) { anchor_of(q_head, qp, ap, al); src = q_head; ++q_head; }
+                        if (la == l) {
+                            if (light) {
+                                lightmask &= lightmask - 1;
+                                anchor_by_wave((u32)__builtin_amdgcn_readfirstlane((int)qkL[(u32)qp]), qp, ap, al);
+                            } else { anchor_of(q_head, qp, ap, al); src = q_head; ++q_head; }
+                        }
                         int sp = 0, sl = 0;
                         if (ls == l) {
                             seedmask &= seedmask - 1;
@@ -620,6 +650,10 @@ struct DevWave {
                     }
                     if (trk && lit + nt <= P.mqd) { adv = nt; return false; }   // mqd = 64: one more tracking step in the next call
                     pos = i + nt;
+                    if (light) {                                                // the queue is behind: whatever it still holds of these steps goes
+                        if (q_head < q_cnt) drop_before(pos);
+                        if (scan_pos < pos) scan_pos = pos;
+                    }
                 }
             }
             // jump to the next queued candidate (lost steps; tracking steps of a round without seed candidates);
