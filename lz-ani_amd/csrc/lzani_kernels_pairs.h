@@ -599,7 +599,7 @@ struct DevWave {
         // and verified by the wave one at a time, only at the steps the round really reaches (as find_event_round does).
         const bool light = trk & refill_now;
         u64 lightmask = 0;
-        if (light) { lightmask = detect_steps(i, nt); refill_now = false; }
+        if (__builtin_expect(light, 0)) { lightmask = detect_steps(i, nt); refill_now = false; }
         for (;;) {
             if (refill_now) {                                        // (the one call site of refill: it is big)
                 if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
@@ -614,7 +614,7 @@ struct DevWave {
                     for (int it = 0; it < 130; ++it) {
                         const int ls = seedmask ? ctz64(seedmask) : 64;
                         int la = 64;
-                        if (light) { if (lightmask) la = ctz64(lightmask); }
+                        if (__builtin_expect(light, 0)) { if (lightmask) la = ctz64(lightmask); }
                         else if (q_head < q_cnt) la = imin(64, __builtin_amdgcn_readlane(a_pos, q_head) - i);
                         if (la >= nt) la = 64;
                         const int l = imin(ls, la);
