@@ -299,12 +299,11 @@ LZ_HD void seed_consider(int p, int m, int ref_pred, int& sp, int& sl)
 // multiplication order as the reference so the comparison in `arbitrate` is bit-exact.
 LZ_HD double pow_not_chance(int len, u32 e)
 {
-    double base = 1.0;
-    if (len < 27) {                      // 1 - 4^-len is exactly 1.0 from len = 27 on (quirk Q5)
-        double p = 1.0;
-        for (int j = 0; j < len; ++j) p *= 0.25;
-        base = 1.0 - p;
-    }
+    // 1 - 4^-len is exactly 1.0 from len = 27 on (quirk Q5), and every power of 1.0 is 1.0: no loop at all for the
+    // long matches of related genomes, where this runs at nearly every event
+    if (len >= 27) return 1.0;
+    // 4^-len by repeated multiplication with 0.25 is exact (a power of two), so it is 2^(-2 len) whichever way it is made
+    double base = 1.0 - __builtin_ldexp(1.0, -2 * len);
     double r = 1.0;
     while (e) {
         if (e & 1u) r *= base;
