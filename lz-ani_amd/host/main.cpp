@@ -319,8 +319,13 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, Filter& flt, P
     if (!aln) {
         vector<int> devs(ng);
         for (int d = 0; d < ng; ++d) devs[d] = P.device + d;
+        if (const char* e = getenv("LZANI_DEVICE_LIST")) {       // rehearsals: e.g. "0,0,0" runs three shards on one GPU
+            devs.clear();
+            for (const auto& x : split(e, ',')) devs.push_back(atoi(x.c_str()));
+            if (devs.empty()) devs.push_back(P.device);
+        }
         lzani_group* grp = nullptr;
-        int rc = E.group_create(&P.lz, (uint32_t)ng, devs.data(), &grp);
+        int rc = E.group_create(&P.lz, (uint32_t)devs.size(), devs.data(), &grp);
         if (rc != LZANI_OK) {
             cerr << "LZ matching failed: lzani_group_create failed with code " << rc
                  << (rc == LZANI_ERR_PARAMS ? " (LZ parameters outside the supported envelope)" : rc == LZANI_ERR_DEVICE ? " (no such GPU, or RCCL could not connect the GPUs)" : "") << endl;
@@ -330,11 +335,11 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, Filter& flt, P
         if (rc == LZANI_OK) rc = E.group_run_rows(grp, n, ref_ids.data(), T.row_off.data(), qids, T.res.data());
         if (rc != LZANI_OK) { cerr << "LZ matching failed: " << E.group_last_error(grp) << endl; E.group_destroy(grp); return false; }
         if (P.verbosity >= 2)
-            for (int d = 0; d < ng; ++d) {
+            for (int d = 0; d < (int)devs.size(); ++d) {
                 lzani_timing t; double gather = 0;
                 if (E.group_get_timing(grp, (uint32_t)d, &t, &gather) == LZANI_OK)
                     cerr << "GPU " << devs[d] << ": " << t.pairs << " pairs, index " << t.index_ms << " ms, pair kernel " << t.pairs_ms << " ms"
-                         << (d == 0 && ng > 1 ? ", RCCL gather " + to_string(gather) + " ms" : string()) << "\n";
+                         << (d == 0 && devs.size() > 1 ? ", gather " + to_string(gather) + " ms" : string()) << "\n";
             }
         E.group_destroy(grp);
         return true;

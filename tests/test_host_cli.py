@@ -323,3 +323,26 @@ def test_config5_heavy_tailed_filter_20k_genomes(tmp_path):
     for qn, rn, mat, lit, aln in sample[:400]:
         qi, ri = int(qn[1:7]), int(rn[1:7])
         assert O.oracle_pair(seq(ri), seq(qi)) == (int(mat), int(lit), int(aln)), (qn, rn)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_group_through_the_binary(tmp_path, monkeypatch):
+    """`lz-ani --gpus n` = lzani_group_run_rows: rows partitioned (cyclic / LPT), a context and a host thread per device,
+    shards gathered on the first device, one copy out.  Rehearsed on this one-GPU box with LZANI_DEVICE_LIST=0,0,0 (three
+    shards on GPU 0; the shards then move by device copies, RCCL refuses duplicate devices): the TSV must be byte-identical
+    to the single-context run, dense and filtered."""
+    fa = os.path.join(U.GOLD, "example", "multifasta.fna")
+    flt = os.path.join(U.GOLD, "example", "fltr.txt")
+    outs = {}
+    for tag, env in (("one", None), ("three", "0,0,0")):
+        if env:
+            monkeypatch.setenv("LZANI_DEVICE_LIST", env)
+        for kind, extra in (("dense", []), ("flt", ["--flt-kmerdb", flt, "0.9", "--out-format", "complete"])):
+            out = str(tmp_path / f"{tag}_{kind}.tsv")
+            p = run(["all2all", "--in-fasta", fa, "-o", out, "-V", "2"] + extra)
+            assert p.returncode == 0, p.stderr[-800:]
+            outs[(tag, kind)] = open(out).read()
+            if env:
+                assert p.stderr.count("GPU 0:") == 3, p.stderr[-600:]
+    assert outs[("one", "dense")] == outs[("three", "dense")] == open(os.path.join(U.GOLD, "example", "ani.tsv")).read()
+    assert outs[("one", "flt")] == outs[("three", "flt")] and outs[("one", "flt")].count("\n") == 27
