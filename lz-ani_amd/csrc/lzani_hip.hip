@@ -76,8 +76,14 @@ struct lzani_ctx {
     u64* d_jkoff = nullptr;                       // per genome: offset of its forward positions (n + 1)
     u64* d_jsoff = nullptr;                       // per genome: offset of its sorted valid keys (n + 1)
     u32* d_jcnt = nullptr;
-    void* d_jtmp = nullptr;
+    void* d_jtmp = nullptr;       // radix-sort scratch (join lists and the sort-based index build)
     size_t jtmp_bytes = 0;
+    // sort-based index build (large directories): keys of the batch's references, unsorted / sorted, per-slot counts and starts
+    bool sort_build = false;
+    unsigned long long* d_ikeys_in = nullptr;
+    unsigned long long* d_ikeys = nullptr;
+    u32* d_icnt = nullptr;
+    u64* d_ibase = nullptr;
     std::vector<u64> jkoff;
     u32 max_slots = 65535;        // gridDim.y limit; LZANI_MAX_SLOTS lowers it (tests force the multi-batch path)
     u64 dir_stride = 0, ent_stride = 0;
@@ -138,6 +144,8 @@ void free_genomes(lzani_ctx* c)
 void free_slabs(lzani_ctx* c)
 {
     hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_bk); hipFree(c->d_tw); hipFree(c->d_status);
+    hipFree(c->d_ikeys_in); hipFree(c->d_ikeys); hipFree(c->d_icnt); hipFree(c->d_ibase);
+    c->d_ikeys_in = c->d_ikeys = nullptr; c->d_icnt = nullptr; c->d_ibase = nullptr;
     c->d_dirz = c->d_ent = c->d_bk = c->d_tw = c->d_status = nullptr; c->slots = 0;
 }
 
@@ -167,13 +175,22 @@ void choose_index_form(lzani_ctx* c)
         c->join_mode = c->tw_stride && c->tw_stride * 4 >= min_bytes && c->P.mqd + c->P.mrd <= 128 &&
                        gbits + c->geo.kb + c->geo.posbits <= 64 && !(nj && *nj == '1');
     }
+    // Sort-based index build where the directory is beyond the LDS-staged build (2^19 buckets): keys of 64 bits with up
+    // to 16 bits of slot number
+    {
+        const char* sm = getenv("LZANI_SORT_INDEX_MIN_DIRBITS");      // tests: 0 forces it at every size
+        const char* ns = getenv("LZANI_NO_SORT_INDEX");
+        c->sort_build = c->d_kmL && c->geo.dirbits >= (sm ? atoi(sm) : 20) && c->geo.kb + c->geo.posbits <= 60 && !(ns && *ns == '1');
+    }
     const char* ms = getenv("LZANI_MAX_SLOTS");
     c->max_slots = ms && atoi(ms) > 0 ? (u32)std::min(65535, atoi(ms)) : 65535u;
+    if (c->sort_build)                                  // the slot number shares the 64-bit key with hash and position
+        c->max_slots = (u32)std::min<u64>(c->max_slots, 1ull << std::min(16, 64 - c->geo.kb - c->geo.posbits));
 }
 
 int ensure_slabs(lzani_ctx* c, u32 want_rows)
 {
-    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride);
+    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride) + (c->sort_build ? (size_t)16 * c->Tmax + 16 : 0);
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     size_t have = c->slots * per_slot;
@@ -186,6 +203,12 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     if (c->bk_stride) HIPCHK(c, hipMalloc(&c->d_bk, (size_t)slots * c->bk_stride * 4));
     if (c->tw_stride) HIPCHK(c, hipMalloc(&c->d_tw, (size_t)slots * c->tw_stride * 4));
     HIPCHK(c, hipMalloc(&c->d_status, (size_t)slots * 4));
+    if (c->sort_build) {
+        HIPCHK(c, hipMalloc(&c->d_ikeys_in, (size_t)slots * c->Tmax * 8));
+        HIPCHK(c, hipMalloc(&c->d_ikeys, (size_t)slots * c->Tmax * 8));
+        HIPCHK(c, hipMalloc(&c->d_icnt, (size_t)slots * 4));
+        HIPCHK(c, hipMalloc(&c->d_ibase, (size_t)slots * 8));
+    }
     c->slots = slots;
     return LZANI_OK;
 }
@@ -277,6 +300,35 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
         c->kmers_ready = true;
         c->tm.index_launches += 1;
         if (c->join_mode) { int rc = build_join_lists(c); if (rc) return rc; }
+    }
+    if (c->sort_build) {
+        // keys -> radix sort (groups of slots below 2^30 keys) -> the tables in one streaming pass
+        const int shift_slot = c->geo.kb + c->geo.posbits, slotbits = ceil_log2((u64)std::max<u32>(rows, 2));
+        const u64 Tm = (u64)c->Tmax;
+        const u32 group = (u32)std::max<u64>(1, std::min<u64>(rows, (1ull << 30) / std::max<u64>(Tm, 1)));
+        HIPCHK(c, hipMemsetAsync(c->d_icnt, 0, (size_t)rows * 4, c->stream));
+        hipLaunchKernelGGL(k_idx_keys, dim3((u32)((Tm + 4095) / 4096), rows), dim3(256), 0, c->stream, ia, c->d_ikeys_in, c->d_icnt, c->Tmax, shift_slot);
+        for (u32 s0 = 0; s0 < rows; s0 += group) {
+            const u64 keys = (u64)std::min(group, rows - s0) * Tm;
+            size_t need = 0;
+            int e = lzani_sort_keys(c->d_ikeys_in + s0 * Tm, c->d_ikeys + s0 * Tm, keys, c->geo.posbits, shift_slot + slotbits, nullptr, &need, c->stream);
+            if (e != 0) return fail(c, LZANI_ERR_DEVICE, "index build: radix sort (size query) failed");
+            if (need > c->jtmp_bytes) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                hipFree(c->d_jtmp); c->d_jtmp = nullptr; c->jtmp_bytes = 0;
+                HIPCHK(c, hipMalloc(&c->d_jtmp, need));
+                c->jtmp_bytes = need;
+            }
+            need = c->jtmp_bytes;
+            e = lzani_sort_keys(c->d_ikeys_in + s0 * Tm, c->d_ikeys + s0 * Tm, keys, c->geo.posbits, shift_slot + slotbits, c->d_jtmp, &need, c->stream);
+            if (e != 0) return fail(c, LZANI_ERR_DEVICE, "index build: radix sort failed");
+        }
+        hipLaunchKernelGGL(k_idx_base, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_icnt, c->d_ibase, rows, group, Tm);
+        hipLaunchKernelGGL(k_idx_from_sorted, dim3((u32)std::min<u64>((Tm + 255) / 256, 8192), rows), dim3(256), 0, c->stream,
+                           ia, c->d_ikeys, c->d_icnt, c->d_ibase, c->d_bk, c->d_tw, c->bk_stride, c->tw_stride);
+        HIPCHK(c, hipGetLastError());
+        c->tm.index_launches += 4;
+        return LZANI_OK;
     }
     const char* nolds = getenv("LZANI_NO_LDS_INDEX");
     const char* ldsmax = getenv("LZANI_LDS_INDEX_MAX_DIRBITS");

@@ -147,6 +147,103 @@ __device__ __forceinline__ bool idx_slot_key(const IdxArgs& a, u32 slot, int p, 
     return true;
 }
 
+// ---- Sort-based index build (directories beyond what k_idx_build stages in LDS) ---------------------------------
+// k_idx_keys -> radix sort (lzani_sort_keys) -> k_idx_base -> k_idx_from_sorted.  One 64-bit key per text position of
+// every reference of the batch, slot || mixed mal-mer hash || position; sorted, the keys of a slot ARE its index:
+// the entries in order, a bucket wherever the hash's top bits change.  Directory, entries, bucket table and tag words
+// come out of one streaming pass; no atomics on the tables (the global-atomics build spends 1.4 ms per 5 Mbp
+// reference on 20 M random atomics and as many scattered stores).
+__global__ void __launch_bounds__(256) k_idx_keys(IdxArgs a, unsigned long long* __restrict__ keys, u32* __restrict__ cnt,
+                                                  int Tmax, int shift_slot)
+{
+    enum { PER_THREAD = 16 };
+    __shared__ u32 s_cnt;
+    const u32 slot = blockIdx.y;
+    const u32 g = a.ref_ids[slot];
+    const int T = ref_text_len(a.G.L[g], a.mrd);
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const u32* km = a.G.kmL + 64 * a.G.nmoff[g];
+    unsigned long long* out = keys + (u64)slot * (u64)Tmax;
+    u32 mine = 0;
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int p = (blockIdx.x * PER_THREAD + k) * 256 + threadIdx.x;
+        if (p >= Tmax) break;
+        const u32 h = p < T ? km[p] : KM_INVALID;
+        const bool ok = h != KM_INVALID;
+        out[p] = ok ? ((unsigned long long)slot << shift_slot) | ((unsigned long long)h << a.geo.posbits) | (unsigned long long)p : ~0ULL;
+        mine += ok;
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&cnt[slot], s_cnt);
+}
+
+// where the sorted keys of every slot begin: the slots of a sort group lie behind each other, the invalid keys of the
+// group behind them all
+__global__ void k_idx_base(const u32* __restrict__ cnt, u64* __restrict__ base, u32 rows, u32 group, u64 Tmax)
+{
+    for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < rows; s += gridDim.x * blockDim.x) {
+        const u32 g0 = s / group * group;
+        u64 at = (u64)g0 * Tmax;
+        for (u32 t = g0; t < s; ++t) at += cnt[t];
+        base[s] = at;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_idx_from_sorted(IdxArgs a, const unsigned long long* __restrict__ sorted,
+                                                         const u32* __restrict__ cnt, const u64* __restrict__ base,
+                                                         u32* __restrict__ bk, u32* __restrict__ tw, u64 bk_stride, u64 tw_stride)
+{
+    const u32 slot = blockIdx.y;
+    const u32 n = cnt[slot], nb = 1u << a.geo.dirbits;
+    const int tb = a.geo.kb - a.geo.dirbits, posbits = a.geo.posbits;
+    const u32 hmask = (u32)lowmask(a.geo.kb), pmask = (u32)lowmask(posbits), tagm = (u32)lowmask(tb) & a.geo.tagmask;
+    u32* dirz = a.dirz + slot * a.dir_stride;
+    u32* ent = a.ent + slot * a.ent_stride;
+    uint4* bks = bk ? reinterpret_cast<uint4*>(bk + slot * bk_stride) : nullptr;
+    u32* tws = tw ? tw + slot * tw_stride : nullptr;
+    const uint4 empty4 = {BK_EMPTY, BK_EMPTY, BK_EMPTY, BK_EMPTY};
+    if (n == 0) {                                        // a reference without a single k-mer: everything empty
+        for (u32 b = blockIdx.x * blockDim.x + threadIdx.x; b <= nb; b += gridDim.x * blockDim.x) {
+            dirz[b] = 0;
+            if (b < nb) { if (bks) bks[b] = empty4; if (tws) tws[b] = 0; }
+        }
+        return;
+    }
+    const unsigned long long* S = sorted + base[slot];
+    for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const unsigned long long e = S[k];
+        const u32 h = ((u32)(e >> posbits)) & hmask, b = h >> tb;
+        const u32 en = ((h & tagm) << posbits) | ((u32)e & pmask);
+        ent[k] = en;
+        const long long pb = k ? (long long)((((u32)(S[k - 1] >> posbits)) & hmask) >> tb) : -1;
+        if ((long long)b != pb) {                        // the first entry of bucket b: it owns the buckets pb+1 .. b
+            for (long long bb = pb + 1; bb <= (long long)b; ++bb) dirz[bb] = k;
+            for (long long bb = pb + 1; bb < (long long)b; ++bb) { if (bks) bks[bb] = empty4; if (tws) tws[bb] = 0; }
+            if (bks) {
+                u32 o[4] = {en, BK_EMPTY, BK_EMPTY, BK_EMPTY};
+                u32 w = 0x80u | (en >> posbits);
+                u32 m = 1;
+                for (; m < 5 && k + m < n; ++m) {
+                    const unsigned long long e2 = S[k + m];
+                    const u32 h2 = ((u32)(e2 >> posbits)) & hmask;
+                    if ((h2 >> tb) != b) break;
+                    if (m < 4) { o[m] = ((h2 & tagm) << posbits) | ((u32)e2 & pmask); w |= (0x80u | (o[m] >> posbits)) << (8 * m); }
+                }
+                if (m > 4) { o[3] = BK_OVERFLOW; w = TW_OVERFLOW; }
+                bks[b] = uint4{o[0], o[1], o[2], o[3]};
+                if (tws) tws[b] = w;
+            }
+        }
+        if (k == n - 1) {                                // the last entry also closes the directory
+            for (long long bb = (long long)b + 1; bb <= (long long)nb; ++bb) dirz[bb] = n;
+            for (long long bb = (long long)b + 1; bb < (long long)nb; ++bb) { if (bks) bks[bb] = empty4; if (tws) tws[bb] = 0; }
+        }
+    }
+}
+
 // (count / fill / zero / sort / buckets walk their range with a grid-stride loop, so that the host can launch
 // them with a handful of blocks per slot when they only serve the few slots k_idx_build could not take)
 __global__ void k_idx_count(IdxArgs a, int Tmax)

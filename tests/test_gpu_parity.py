@@ -315,7 +315,7 @@ def test_index_forms(monkeypatch, env):
             e += 1
 
 
-@pytest.mark.parametrize("env", [{}, {"LZANI_NO_LDS_INDEX": "1"}], ids=["lds-build", "global-atomics"])
+@pytest.mark.parametrize("env", [{}, {"LZANI_NO_LDS_INDEX": "1"}, {"LZANI_SORT_INDEX_MIN_DIRBITS": "0"}], ids=["lds-build", "global-atomics", "sort-build"])
 def test_index_build_paths(monkeypatch, env):
     """k_idx_build (one block per reference through LDS) and its fallback: references the LDS build cannot take
     (a poly-A genome: one bucket holds every k-mer; a long tandem repeat; a genome with a 30 kbp low-complexity
@@ -355,8 +355,12 @@ def test_index_build_paths(monkeypatch, env):
     assert np.array_equal(gpu_all2all(seqs[:4]), O.oracle_all2all(seqs[:4], None, threads=16))
 
 
-def test_index_build_mid_size_directories():
-    """k_idx_build beyond viral size: 2^18 and 2^19 buckets (16 and 32 bucket ranges per reference)."""
+@pytest.mark.parametrize("env", [{}, {"LZANI_SORT_INDEX_MIN_DIRBITS": "0"}], ids=["lds-build", "sort-build"])
+def test_index_build_mid_size_directories(monkeypatch, env):
+    """k_idx_build beyond viral size: 2^18 and 2^19 buckets (16 and 32 bucket ranges per reference); and the sort-based
+    build (keys -> radix sort -> one streaming pass), which takes over from 2^20 buckets on, forced at these sizes."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     st = SG.Stream(8)
     a = (st.u64(100_000) % np.uint64(4)).astype(np.uint8)
     b = (st.u64(230_000) % np.uint64(4)).astype(np.uint8)
