@@ -69,7 +69,7 @@ def test_model_regions_stream_equals_calc_regions():
 @pytest.mark.parametrize("words", [0, 1])
 def test_lane_serial_policy(words):
     """LaneWave (lzani_core.h): the same machine driven by one lane per pair with word-parallel bit tricks
-    and a second (msl) index -- the formulation of the thread-per-pair kernel variant."""
+    and a second (msl) index -- a second, independent host model (round 1 also ran it as a thread-per-pair GPU kernel)."""
     import ctypes as C
     lib = U.model_lib()
 
