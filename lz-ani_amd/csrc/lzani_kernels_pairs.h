@@ -592,14 +592,53 @@ struct DevWave {
                 }
             }
         }
-        // everything else: refills, seed candidates to verify, candidates the lanes could not settle, the end of the query
         int pos = i, guard = 0;
         bool merge_done = false;
-        // A tracking round the queue does not cover runs LIGHT: its anchors are detected for the tracking steps alone
-        // and verified by the wave one at a time, only at the steps the round really reaches (as find_event_round does).
-        const bool light = trk & refill_now;
-        u64 lightmask = 0;
-        if (__builtin_expect(light, 0)) { lightmask = detect_steps(i, nt); refill_now = false; }
+        if (trk & refill_now) {
+            // A tracking round the queue does not cover (the scan has jumped over it: an extension moved, a related
+            // stretch) runs LIGHT, on its own: its anchors are detected for the tracking steps alone and verified by the
+            // wave one at a time, only at the steps the round really reaches (as find_event_round does) -- resolving 64
+            // candidates per event where every position is one would be wasted.  Kept apart from the loop below so that
+            // neither shapes the other's registers.
+            seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk);
+            u64 lightmask = detect_steps(i, nt);
+            for (int it = 0; it < 130; ++it) {
+                const int ls = seedmask ? ctz64(seedmask) : 64;
+                const int la = lightmask ? ctz64(lightmask) : 64;
+                const int l = imin(ls, la);
+                if (l >= 64) break;
+                const int qp = i + l;
+                int ap = 0, al = 0;
+                if (la == l) {
+                    lightmask &= lightmask - 1;
+                    anchor_by_wave((u32)__builtin_amdgcn_readfirstlane((int)qkL[(u32)qp]), qp, ap, al);
+                }
+                int sp = 0, sl = 0;
+                if (ls == l) {
+                    seedmask &= seedmask - 1;
+                    const int ref_pred = r_end + lit + l;
+                    u64 d0 = 0, d1 = 0;
+                    const u32 qkl = (u32)__builtin_amdgcn_readlane((int)qk, l);
+                    if (qkl != KM_INVALID) seed_candidates(qkl, lit + l + P.mrd, rk0, rk1, d0, d1);
+                    while (d0 | d1) {
+                        int idx;
+                        if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
+                        else { idx = 64 + ctz64(d1); d1 &= d1 - 1; }
+                        seed_consider(r_end + idx, wave_equal_len(r_end + idx, qp, P.msl), ref_pred, sp, sl);
+                    }
+                }
+                arbitrate(P, R.len, lit + l, ap, al, sp, sl);
+                if (sl >= P.msl) { adv = l; bpos = sp; blen = sl; return true; }
+            }
+            if (lit + nt <= P.mqd) { adv = nt; return false; }       // mqd = 64: one more tracking step in the next call
+            // no tracking step hits: on in lost mode; whatever the queue still holds of these steps goes
+            pos = i + nt;
+            if (q_head < q_cnt) drop_before(pos);
+            if (scan_pos < pos) scan_pos = pos;
+            refill_now = false;
+            round_done = true; merge_done = true;
+        }
+        // everything else: refills, seed candidates to verify, candidates the lanes could not settle, the end of the query
         for (;;) {
             if (refill_now) {                                        // (the one call site of refill: it is big)
                 if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
@@ -609,24 +648,18 @@ struct DevWave {
             if (!round_done) { seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk); round_done = true; }
             if (!merge_done) {
                 merge_done = true;
-                if (seedmask != 0 || (trk && lit + nt <= P.mqd) || light) {
-                    // tracking steps with a seed candidate and / or an anchor (queued, or detected just now), in step order
+                if (seedmask != 0 || (trk && lit + nt <= P.mqd)) {
+                    // tracking steps with a seed candidate and / or a queued anchor, in step order
                     for (int it = 0; it < 130; ++it) {
                         const int ls = seedmask ? ctz64(seedmask) : 64;
                         int la = 64;
-                        if (__builtin_expect(light, 0)) { if (lightmask) la = ctz64(lightmask); }
-                        else if (q_head < q_cnt) la = imin(64, __builtin_amdgcn_readlane(a_pos, q_head) - i);
+                        if (q_head < q_cnt) la = imin(64, __builtin_amdgcn_readlane(a_pos, q_head) - i);
                         if (la >= nt) la = 64;
                         const int l = imin(ls, la);
                         if (l >= 64) break;
                         const int qp = i + l;
                         int ap = 0, al = 0, src = -1;
-                        if (la == l) {
-                            if (light) {
-                                lightmask &= lightmask - 1;
-                                anchor_by_wave((u32)__builtin_amdgcn_readfirstlane((int)qkL[(u32)qp]), qp, ap, al);
-                            } else { anchor_of(q_head, qp, ap, al); src = q_head; ++q_head; }
-                        }
+                        if (la == l) { anchor_of(q_head, qp, ap, al); src = q_head; ++q_head; }
                         int sp = 0, sl = 0;
                         if (ls == l) {
                             seedmask &= seedmask - 1;
@@ -650,10 +683,6 @@ struct DevWave {
                     }
                     if (trk && lit + nt <= P.mqd) { adv = nt; return false; }   // mqd = 64: one more tracking step in the next call
                     pos = i + nt;
-                    if (light) {                                                // the queue is behind: whatever it still holds of these steps goes
-                        if (q_head < q_cnt) drop_before(pos);
-                        if (scan_pos < pos) scan_pos = pos;
-                    }
                 }
             }
             // jump to the next queued candidate (lost steps; tracking steps of a round without seed candidates);
