@@ -171,7 +171,7 @@ void choose_index_form(lzani_ctx* c)
         const char* nj = getenv("LZANI_NO_JOIN");
         const char* jm = getenv("LZANI_JOIN_MIN_BYTES");
         const u64 min_bytes = jm ? strtoull(jm, nullptr, 10) : (8ull << 20);
-        const int gbits = ceil_log2((u64)std::max<u32>(c->n_pending, 2));
+        const int gbits = ceil_log2((u64)c->n_pending + 1);          // the all-ones genome number is the invalid key's
         c->join_mode = c->tw_stride && c->tw_stride * 4 >= min_bytes && c->P.mqd + c->P.mrd <= 128 &&
                        gbits + c->geo.kb + c->geo.posbits <= 64 && !(nj && *nj == '1');
     }
@@ -185,7 +185,7 @@ void choose_index_form(lzani_ctx* c)
     const char* ms = getenv("LZANI_MAX_SLOTS");
     c->max_slots = ms && atoi(ms) > 0 ? (u32)std::min(65535, atoi(ms)) : 65535u;
     if (c->sort_build)                                  // the slot number shares the 64-bit key with hash and position
-        c->max_slots = (u32)std::min<u64>(c->max_slots, 1ull << std::min(16, 64 - c->geo.kb - c->geo.posbits));
+        c->max_slots = (u32)std::min<u64>(c->max_slots, (1ull << std::min(16, 64 - c->geo.kb - c->geo.posbits)) - 1);
 }
 
 int ensure_slabs(lzani_ctx* c, u32 want_rows)
@@ -232,7 +232,10 @@ int build_join_lists(lzani_ctx* c)
     }
     int Lmax = 0;
     for (u32 g = 0; g < n; ++g) Lmax = std::max(Lmax, c->L[g]);
-    const int shift_g = c->geo.kb + c->geo.posbits, gbits = ceil_log2((u64)std::max<u32>(n, 2));
+    // An invalid key is all ones; the sort looks at the bits [posbits, shift_g + gbits) only, so no real genome number may
+    // be all ones in gbits bits, or its keys with the all-ones hash would be indistinguishable from the invalid keys of
+    // the genomes before it (found by the fuzz at n = 4: genome 3 lost the k-mers of its last bucket)
+    const int shift_g = c->geo.kb + c->geo.posbits, gbits = ceil_log2((u64)n + 1);
     HIPCHK(c, hipMemsetAsync(c->d_jcnt, 0, (size_t)n * 4, c->stream));
     for (u32 g0 = 0; g0 < n && Lmax > 0; g0 += 32768) {
         const u32 cnt = std::min<u32>(32768, n - g0);
@@ -303,7 +306,7 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
     }
     if (c->sort_build) {
         // keys -> radix sort (groups of slots below 2^30 keys) -> the tables in one streaming pass
-        const int shift_slot = c->geo.kb + c->geo.posbits, slotbits = ceil_log2((u64)std::max<u32>(rows, 2));
+        const int shift_slot = c->geo.kb + c->geo.posbits, slotbits = ceil_log2((u64)rows + 1);     // (no slot number is all ones: see build_join_lists)
         const u64 Tm = (u64)c->Tmax;
         const u32 group = (u32)std::max<u64>(1, std::min<u64>(rows, (1ull << 30) / std::max<u64>(Tm, 1)));
         HIPCHK(c, hipMemsetAsync(c->d_icnt, 0, (size_t)rows * 4, c->stream));

@@ -569,6 +569,28 @@ def test_join_form_of_candidate_detection(monkeypatch):
             e += 1
 
 
+def test_last_slot_number_is_not_the_invalid_key(monkeypatch):
+    """Found by the differential fuzz (tools/fuzz_gpu.py, seed 1202 case 1361) with the join and the sort-based index
+    build forced on: both sort 64-bit keys `number || hash || position` whose invalid form is all ones, looking only at
+    the number and hash bits -- so the LAST genome / slot of a power-of-two count (here 2) had the all-ones number and
+    lost the k-mers of its all-ones hash bucket to the invalid keys.  Two unrelated ~65 kbp genomes at mal = 10."""
+    z = np.load(os.path.join(U.GOLD, "fuzz_last_slot_all_ones.npz"))
+    prm = dict(zip(("mal", "msl", "mrd", "mqd", "reg", "aw", "am", "ar"), [int(x) for x in z["prm"]]))
+    seqs = []
+    for name in ("a", "b"):
+        pk = z[name]
+        s = np.stack([pk & 3, (pk >> 2) & 3, (pk >> 4) & 3, (pk >> 6) & 3], axis=1).reshape(-1)[: int(z[name + "_len"][0])]
+        seqs.append(np.ascontiguousarray(s, dtype=np.uint8))
+    want = O.oracle_all2all(seqs, prm, threads=4)
+    for env in ({}, {"LZANI_JOIN_MIN_BYTES": "1"}, {"LZANI_SORT_INDEX_MIN_DIRBITS": "0"},
+                {"LZANI_JOIN_MIN_BYTES": "1", "LZANI_SORT_INDEX_MIN_DIRBITS": "0"}):
+        for k in ("LZANI_JOIN_MIN_BYTES", "LZANI_SORT_INDEX_MIN_DIRBITS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert np.array_equal(gpu_all2all(seqs, prm), want), env
+
+
 def test_device_group_single_process(monkeypatch):
     """lzani_group_* (what `lz-ani --gpus n` calls): rows partitioned over the devices of the group (cyclic for dense
     rows, LPT for filtered ones), one context and host thread per device, shards gathered on the first device,
