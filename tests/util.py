@@ -214,6 +214,20 @@ def fuzz_case_medium(st):
     return prm, seqs
 
 
+def fuzz_case_large(st):
+    """Like fuzz_case_medium at 0.3-1.2 Mbp: directories of 2^20 buckets and more (the sort-based index build) and, from
+    ~0.5 Mbp on, tag words of 8 MB (candidates by the join): an ancestor, a mutated copy, a stranger."""
+    prm, _ = fuzz_case_medium(st)
+    L = st.randint(300_000, 1_200_000)
+    base = (st.u64(L) % np.uint64(4)).astype(np.uint8)
+    g = SG.mutate(base, 0.01 + 0.1 * st.one(), st).copy()
+    if st.one() < 0.5:
+        a = st.randint(0, len(g) - 500)
+        g[a:a + st.randint(1, 300)] = 5
+    other = (st.u64(st.randint(300_000, 1_200_000)) % np.uint64(4)).astype(np.uint8)
+    return prm, [base, np.ascontiguousarray(g), other]
+
+
 def fuzz_case(st):
     """One random differential case: LZ parameters inside the engine's envelope with mqd <= mrd (beyond
     that the reference reads past the end of its reference text, parser.cpp:288/713, and its answer

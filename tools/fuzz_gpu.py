@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Long differential fuzz of the HIP path against the oracle.  Usage: tools/fuzz_gpu.py [seed] [seconds] [medium]
-`medium`: 8-70 kbp genomes (tag words, bucket table, LDS index build in use) instead of the tiny ones."""
+"""Long differential fuzz of the HIP path against the oracle.  Usage: tools/fuzz_gpu.py [seed] [seconds] [medium|large]
+`medium`: 8-70 kbp genomes (tag words, bucket table, LDS index build in use) instead of the tiny ones;
+`large`: 0.3-1.2 Mbp (sort-based index build, join form of candidate detection)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("lz-ani_amd", "oracle", "tools", "tests"):
@@ -14,18 +15,19 @@ import util as U
 st = SG.Stream(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
 medium = len(sys.argv) > 3 and sys.argv[3] == "medium"
+large = len(sys.argv) > 3 and sys.argv[3] == "large"
 t0, it, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     it += 1
-    prm, seqs = U.fuzz_case_medium(st) if medium else U.fuzz_case(st)
+    prm, seqs = U.fuzz_case_large(st) if large else U.fuzz_case_medium(st) if medium else U.fuzz_case(st)
     eng = L.Engine(prm)
     eng.set_genomes(seqs)
     got = eng.all2all()
-    want = O.oracle_all2all(seqs, prm, threads=16 if medium else 4)
+    want = O.oracle_all2all(seqs, prm, threads=16 if (medium or large) else 4)
     if not np.array_equal(got, want):
         bad += 1
         print("MISMATCH", prm, [len(s) for s in seqs], np.argwhere((got != want).any(axis=2))[:3].tolist(), flush=True)
-    if it % 4 == 0:                                   # the alignment instantiation: regions of one row
+    if it % 4 == 0 and not large:                     # the alignment instantiation: regions of one row (the oracle wrapper holds 4,096 regions per pair: not at Mbp sizes)
         n = len(seqs)
         r = it % n
         ref_ids, row_off = L.dense_rows(n, [r])
