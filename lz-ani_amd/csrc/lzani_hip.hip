@@ -134,7 +134,7 @@ int fail(lzani_ctx* c, int code, const std::string& msg)
 void free_genomes(lzani_ctx* c)
 {
     hipFree(c->d_t2); hipFree(c->d_nm); hipFree(c->d_nmoff); hipFree(c->d_L); hipFree(c->d_kmL); hipFree(c->d_kmS); hipFree(c->d_hasN);
-    hipFree(c->d_jkeys_in); hipFree(c->d_jkeys); hipFree(c->d_jkoff); hipFree(c->d_jsoff); hipFree(c->d_jcnt); hipFree(c->d_jtmp);
+    hipFree(c->d_jkeys); hipFree(c->d_jkoff); hipFree(c->d_jsoff); hipFree(c->d_jcnt); hipFree(c->d_jtmp);
     c->d_jkeys_in = c->d_jkeys = nullptr; c->d_jkoff = c->d_jsoff = nullptr; c->d_jcnt = nullptr; c->d_jtmp = nullptr; c->jtmp_bytes = 0;
     c->join_mode = c->join_ready = false;
     c->d_hasN = nullptr;
@@ -217,19 +217,31 @@ GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmo
 
 // Join form: the k-mer list of every genome as a query, sorted by (genome, bucket) -- k_join_keys + hipCUB radix sort,
 // once per run, behind k_kmers (it is part of the path's work like the k-mer words it is made from).
+// the resident part of the join lists (the sorted keys: 8 B per forward position), allocated before the index slabs are
+// sized so that those see what is really left
+int alloc_join_lists(lzani_ctx* c)
+{
+    const u32 n = c->n;
+    if (c->d_jkoff) return LZANI_OK;
+    c->jkoff.assign((size_t)n + 1, 0);
+    for (u32 g = 0; g < n; ++g) c->jkoff[g + 1] = c->jkoff[g] + (u64)c->L[g];
+    HIPCHK(c, hipMalloc(&c->d_jkoff, ((size_t)n + 1) * 8));
+    HIPCHK(c, hipMalloc(&c->d_jsoff, ((size_t)n + 1) * 8));
+    HIPCHK(c, hipMalloc(&c->d_jcnt, (size_t)n * 4));
+    HIPCHK(c, hipMalloc(&c->d_jkeys, std::max<u64>(c->jkoff[n], 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(c->d_jkoff, c->jkoff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    return LZANI_OK;
+}
+
 int build_join_lists(lzani_ctx* c)
 {
     const u32 n = c->n;
-    if (!c->d_jkoff) {
-        c->jkoff.assign((size_t)n + 1, 0);
-        for (u32 g = 0; g < n; ++g) c->jkoff[g + 1] = c->jkoff[g] + (u64)c->L[g];
-        HIPCHK(c, hipMalloc(&c->d_jkoff, ((size_t)n + 1) * 8));
-        HIPCHK(c, hipMalloc(&c->d_jsoff, ((size_t)n + 1) * 8));
-        HIPCHK(c, hipMalloc(&c->d_jcnt, (size_t)n * 4));
-        HIPCHK(c, hipMalloc(&c->d_jkeys_in, std::max<u64>(c->jkoff[n], 1) * 8));
-        HIPCHK(c, hipMalloc(&c->d_jkeys, std::max<u64>(c->jkoff[n], 1) * 8));
-        HIPCHK(c, hipMemcpyAsync(c->d_jkoff, c->jkoff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    }
+    int rc0 = alloc_join_lists(c);
+    if (rc0) return rc0;
+    // the unsorted keys live for the duration of the sort only (as much again as the lists themselves)
+    DevBuf<unsigned long long> keys_in;
+    HIPCHK(c, keys_in.alloc(std::max<u64>(c->jkoff[n], 1)));
+    c->d_jkeys_in = keys_in.p;
     int Lmax = 0;
     for (u32 g = 0; g < n; ++g) Lmax = std::max(Lmax, c->L[g]);
     // An invalid key is all ones; the sort looks at the bits [posbits, shift_g + gbits) only, so no real genome number may
@@ -277,7 +289,8 @@ int build_join_lists(lzani_ctx* c)
     // (a genome's list ends after its valid keys -- d_jcnt -- not where the next list begins: between two groups sit the
     // invalid keys of the first)
     HIPCHK(c, hipMemcpyAsync(c->d_jsoff, soff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));        // (also: keys_in is released below)
+    c->d_jkeys_in = nullptr;
     c->tm.index_launches += 2;
     return LZANI_OK;
 }
@@ -391,7 +404,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     if (n_pairs == 0) return LZANI_OK;
 
     HIPCHK(c, hipSetDevice(c->dev));
-    int rc = ensure_slabs(c, n_rows);
+    int rc = c->join_mode ? alloc_join_lists(c) : LZANI_OK;
+    if (rc) return rc;
+    rc = ensure_slabs(c, n_rows);
     if (rc) return rc;
 
     // Batches of `slots` rows (one index slab per row).  Everything the batches need from the host -- row tables

@@ -1,7 +1,9 @@
 // synth5 -- seeded synthetic genome sets with HEAVY-TAILED family sizes and the matching kmer-db filter file
 // (SURVEY 8(d) config 5 / BASELINE configs[4]: "100,000 viral genomes with --flt-kmerdb prefilter at 0.3").
 //
-//   synth5 <n> <seed> <lmin> <lmax> <out.fna> <out.kmerdb> <out.bin> [max_family=1000] [threshold=0.3]
+//   synth5 <n> <seed> <lmin> <lmax> <out.fna> <out.kmerdb> <out.bin> [max_family=1000] [threshold=0.3] [fixed_family=0] [dmin=0.01] [dmax=0.15]
+//   (fixed_family > 0: every family has that many members -- BASELINE configs[3]: 1,000 x 5 Mbp in families of 10,
+//   d ~ U(0.005, 0.08): synth5 1000 3 4500000 5500000 ... 1000 0.3 10 0.005 0.08)
 //
 // Families: 40 % singletons, 40 % of size 2-10, 15 % of size 11-100, 5 % of size 101-max_family.  Member 0 of a
 // family is a uniform random ancestor of length U[lmin,lmax]; the others are the ancestor with substitutions at
@@ -70,6 +72,8 @@ int main(int argc, char** argv)
     const u64 lmin = strtoull(argv[3], 0, 10), lmax = strtoull(argv[4], 0, 10);
     const u64 maxfam = argc > 8 ? strtoull(argv[8], 0, 10) : 1000;
     const double thr = argc > 9 ? atof(argv[9]) : 0.3;
+    const u64 fixed_fam = argc > 10 ? strtoull(argv[10], 0, 10) : 0;
+    const double dmin = argc > 11 ? atof(argv[11]) : 0.01, dmax = argc > 12 ? atof(argv[12]) : 0.15;
     FILE* ffa = fopen(argv[5], "wb");
     FILE* fdb = fopen(argv[6], "wb");
     FILE* fbin = fopen(argv[7], "wb");
@@ -85,6 +89,7 @@ int main(int argc, char** argv)
     for (u64 at = 0; at < n;) {
         const double u = r.uni();
         u64 sz = u < 0.4 ? 1 : u < 0.8 ? r.range(2, 10) : u < 0.95 ? r.range(11, 100) : r.range(101, std::max<u64>(101, maxfam));
+        if (fixed_fam) sz = fixed_fam;
         sz = std::min(sz, n - at);
         fam_first.push_back(at); fam_size.push_back(sz);
         at += sz;
@@ -121,7 +126,7 @@ int main(int argc, char** argv)
         for (u64 m = 0; m < fam_size[f]; ++m) {
             const u64 i = fam_first[f] + m;
             const std::vector<uint8_t>* s = &anc;
-            if (m) { div[i] = 0.01 + 0.14 * r.uni(); mutate(anc, div[i], r, g); s = &g; }
+            if (m) { div[i] = dmin + (dmax - dmin) * r.uni(); mutate(anc, div[i], r, g); s = &g; }
             off[i + 1] = off[i] + s->size();
             fwrite(s->data(), 1, s->size(), fbin);
             fputc('>', ffa); fputs(names[i].c_str(), ffa); fputc('\n', ffa);
