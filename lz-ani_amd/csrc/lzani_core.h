@@ -23,6 +23,7 @@
 // the tests have two host policies of their own (tests/model/: lane-emulating, and lane-serial).
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -549,10 +550,15 @@ LZ_HD bool ext_rec_null_bwd(u32 rec, int reach, int aw)
 //   int  best_split(Lm, Rm, to_scan) argmax_s popc(Lm & low(s)) + popc(Rm >> s), last max wins
 //   void mism2(qa, ra, da, na, qb, rb, db, nb, A, B)   two mismatch masks in one fetch: bit j of A = mismatch of
 //                                   Q[qa + da*j] vs R[ra + da*j] for j < na (d = +1 forward, -1 backward), same for B
+//   int  null_chain(...)            optional (static constexpr bool NULL_CHAIN = true): see run()
 //   bool ext_record(u32&)           the null-extension record (null_ext_record) of the event find_event just
 //                                   returned, if the policy has one (the anchor queue of the device)
 //   void stamp(section)             profiling hook (no-op outside the LZANI_STAMPS diagnostic build)
 //   void emit_region(RegionCoords)  ALN only: one region of calc_regions (length >= reg)
+// a policy may bring a hand-scheduled loop over runs of null events (DevWave::null_chain); policies without one say nothing
+template <class W, class = void> struct wave_has_null_chain : std::false_type {};
+template <class W> struct wave_has_null_chain<W, std::void_t<decltype(W::NULL_CHAIN)>> : std::bool_constant<W::NULL_CHAIN> {};
+
 template <class W, bool ALN = false>
 struct PairMachine {
     W& w;
@@ -698,7 +704,22 @@ struct PairMachine {
             if (++rounds > D + 8) { LZ_GUARD_TRIP(3); out[0] = -1; out[1] = i; out[2] = lit; return; }
             int adv = 0, bpos = 0, blen = 0;
             w.stamp(1);
-            const bool hit = w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);
+            int in_hand = 0;
+            if constexpr (wave_has_null_chain<W>::value && !ALN) {
+                // Straight after an event (tracking, nothing skipped yet) the policy may run the whole cycle
+                // "tracking round without a seed candidate -> next plain candidate -> distant null event over a dropped
+                // short region" for as many events as it lasts: exactly the updates of the null event below, nothing
+                // else touched; what it leaves unfinished it hands back (the round done, or the event found).
+                if (trk & (lit == 0)) {
+                    int last_blen = 0;
+                    in_hand = w.null_chain(i, r_end, prev_rs, prev_re, pre_lit, last_blen, adv, bpos, blen);
+                    if (last_blen) { g.cl = last_blen; g.clit = 0; g.nl = 0; }     // discard + the match of the last null event
+                }
+            }
+            const bool hit = in_hand == 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);
+#if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
+            w.st[6] += hit && in_hand != 2;
+#endif
             i += adv; lit += adv;
             if (!hit) {
                 if (lit > P.mqd) trk = false;

@@ -21,6 +21,9 @@ __device__ int g_guard_trip = 0;   // see LZ_GUARD_TRIP in lzani_core.h
 #ifdef LZANI_STAMPS
 __device__ unsigned long long g_stamp_acc[8];
 #endif
+#ifdef LZANI_CHAIN_STATS
+__device__ unsigned long long g_chain_stats[8];
+#endif
 
 int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_t n, int begin_bit, int end_bit,
                     void* tmp, size_t* tmp_bytes, hipStream_t stream);      // lzani_sort.hip (hipCUB radix sort)
@@ -558,6 +561,17 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         fprintf(stderr, "\n");
         unsigned long long z[8] = {0};
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof z));
+    }
+#endif
+#ifdef LZANI_CHAIN_STATS
+    {
+        unsigned long long acc[8], z[8] = {0};
+        HIPCHK(c, hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_chain_stats), sizeof acc));
+        const char* nm[8] = {"chain_calls", "commits", "exit_nothing", "exit_seed", "exit_not_plain", "exit_event", "events_general", "refills"};
+        fprintf(stderr, "[lzani chain] pairs=%llu per pair:", (unsigned long long)n_pairs);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f", nm[k], (double)acc[k] / (double)n_pairs);
+        fprintf(stderr, "\n");
+        HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stats), z, sizeof z));
     }
 #endif
     int trip = 0;

@@ -21,8 +21,12 @@ enum { AQ_NONE = 0x7FFFFFFF };
 
 // FAST: per-position k-mer words exist;  BK: the bucket table and its tag words exist;  JOIN: the candidates of a pair
 // come from a join with the query's sorted k-mer list (long genomes) instead of a probe per query position
-template <bool FAST, bool BK = false, bool JOIN = false>
+// the wave's vote as the compare result itself (HIP's __ballot goes through an int: v_cndmask 0/1 + v_cmp_ne per vote)
+__device__ __forceinline__ u64 wballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+template <bool FAST, bool BK = false, bool JOIN = false, bool CHAIN = false>
 struct DevWave {
+    static constexpr bool NULL_CHAIN = CHAIN;
     const Params& P;
     TextView R, Q;
     IndexView I;
@@ -47,6 +51,13 @@ struct DevWave {
     unsigned long long* cand_bits = nullptr;
     int a_pos = AQ_NONE, a_len = 0;
     u32 a_ref = 0;
+#ifdef LZANI_CHAIN_STATS
+    unsigned st[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // diagnostic build: chain calls, commits, exits by kind, events by the general path, refills
+#endif
+    // the tracking round null_chain has done for the next find_event call (CHAIN)
+    bool pre_round = false;
+    u64 pre_seed = 0;
+    u32 pre_rk0 = KM_INVALID, pre_rk1 = KM_INVALID, pre_qk = KM_INVALID;
     __device__ __forceinline__ void emit_region(const RegionCoords& c) const
     {
         // One slot per wave, reserved by ONE lane and without a lane-dependent branch (see the note at the ticket fetch:
@@ -115,11 +126,11 @@ struct DevWave {
     }
     __device__ __forceinline__ u64 mism_fwd(int q0, int r0, int n) const
     {
-        return __ballot((lane < n) & lane_mismatch(r0 + lane, q0 + lane));
+        return wballot((lane < n) & lane_mismatch(r0 + lane, q0 + lane));
     }
     __device__ __forceinline__ u64 mism_bwd(int q0, int r0, int n) const
     {
-        return __ballot((lane < n) & lane_mismatch(r0 - 1 - lane, q0 - 1 - lane));
+        return wballot((lane < n) & lane_mismatch(r0 - 1 - lane, q0 - 1 - lane));
     }
     // two masks, four independent loads in flight, one wait
     __device__ __forceinline__ void mism2(int qa, int ra, int da, int na, int qb, int rb, int db, int nb, u64& A, u64& B) const
@@ -134,8 +145,8 @@ struct DevWave {
             ma = !sym_match(R, rpa, Q, qpa);
             mb = !sym_match(R, rpb, Q, qpb);
         }
-        A = __ballot((lane < na) & ma);
-        B = __ballot((lane < nb) & mb);
+        A = wballot((lane < na) & ma);
+        B = wballot((lane < nb) & mb);
     }
     // Close-seed search of the tracking steps of a round (replaces the ht_short bucket walk, parser.cpp:548-580).
     // rk0/rk1 = msl-mers of the window positions r_end+lane / r_end+64+lane, qk = msl-mer of this lane's step
@@ -173,8 +184,8 @@ struct DevWave {
     // window positions idx < lim (the step's own window) whose msl-mer equals the step's (qkl, wave-uniform)
     __device__ __forceinline__ void seed_candidates(u32 qkl, int lim, u32 rk0, u32 rk1, u64& d0, u64& d1) const
     {
-        d0 = __ballot(rk0 == qkl) & lowmask(lim);
-        d1 = __ballot(rk1 == qkl) & lowmask(lim - 64);
+        d0 = wballot(rk0 == qkl) & lowmask(lim);
+        d1 = wballot(rk1 == qkl) & lowmask(lim - 64);
     }
 
     __device__ __forceinline__ u64 bcast64(u64 v, int l) const      // readlane returns a signed int: widen as u32
@@ -203,7 +214,7 @@ struct DevWave {
         int bp = 0, bl = 0;
         if (lane < n)
             eval_step(P, R, Q, I, i + lane, trk && (lit + lane <= P.mqd), r_end, lit + lane, bp, bl);
-        u64 hit = __ballot(lane < n && bl >= P.msl);
+        u64 hit = wballot(lane < n && bl >= P.msl);
         if (!hit) { ev_lane = n; return false; }
         ev_lane = ctz64(hit);
         bpos = __builtin_amdgcn_readlane(bp, ev_lane);     // ev_lane is wave-uniform (from the ballot)
@@ -318,7 +329,7 @@ struct DevWave {
         stamp(2);
         bool shit = false;
         if (W > 0) shit = seed_prefilter(rk0, rk1, qk);
-        u64 todo = __ballot(ac != 0 || shit);
+        u64 todo = wballot(ac != 0 || shit);
         stamp(7);
         const u32 pm = (u32)lowmask(I.posbits);
         while (todo) {
@@ -381,6 +392,9 @@ struct DevWave {
     }
     __device__ __forceinline__ void refill(int from)
     {
+#ifdef LZANI_CHAIN_STATS
+        st[7] += 1;
+#endif
         u32* const cq = bitmap + SEED_BM_WORDS;
         const int tb = I.kb - I.dirbits;
         scan_pos = imax(scan_pos, from);
@@ -425,7 +439,7 @@ struct DevWave {
                 const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;                     // its lowest flag is exact
                 const bool ovf = w[c] == TW_OVERFLOW;
                 const bool cnd = valid[c] & ((z != 0) | ovf);
-                const u64 bal = __ballot(cnd);
+                const u64 bal = wballot(cnd);
                 if (bal) {
                     const int at = ncand + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
                     const bool cplx = ovf | ((z & (z - 1)) != 0);                       // bucket overflow, or the tag in two slots
@@ -488,6 +502,20 @@ struct DevWave {
         // what a distant event at this candidate needs to see that neither extension moves, worked out now, by the
         // lane, for the whole batch at once
         a_ext = (simple & !lng) ? null_ext_record(P, R, Q, qp, pos, al0) : (u32)EXT_REC_NONE;
+        // A candidate the lane has resolved to a match shorter than mal is no anchor and never an event -- the tag of
+        // another k-mer in the bucket, about as many per pair as there are true anchors: it leaves the queue here, all
+        // of a batch in one stable compaction (lane permute, no LDS memory), instead of costing the sequential scan a
+        // step each.  (The lanes behind the last kept candidate receive leftovers; their position says AQ_NONE.)
+        const bool kept = live & !(simple & !lng & (al0 < P.mal));
+        const u64 keep = wballot(kept);
+        if (keep != lowmask(q_cnt)) {
+            const int to = 4 * (kept ? (int)__builtin_amdgcn_mbcnt_hi((u32)(keep >> 32), __builtin_amdgcn_mbcnt_lo((u32)keep, 0u)) : 63);
+            q_cnt = popc64(keep);
+            const int mp = __builtin_amdgcn_ds_permute(to, a_pos), ml = __builtin_amdgcn_ds_permute(to, a_len);
+            const int mr = __builtin_amdgcn_ds_permute(to, (int)a_ref), mx = __builtin_amdgcn_ds_permute(to, (int)a_ext);
+            a_pos = lane < q_cnt ? mp : (int)AQ_NONE;
+            a_len = ml; a_ref = (u32)mr; a_ext = (u32)mx;
+        }
     }
     __device__ __forceinline__ bool ext_record(u32& x) const
     {
@@ -505,7 +533,7 @@ struct DevWave {
     // the queue without the candidates before query position pos
     __device__ __forceinline__ void drop_before(int pos)
     {
-        const u64 m = __ballot((lane >= q_head) & (a_pos >= pos));          // lanes beyond q_cnt hold AQ_NONE
+        const u64 m = wballot((lane >= q_head) & (a_pos >= pos));          // lanes beyond q_cnt hold AQ_NONE
         q_head = m ? ctz64(m) : 64;
     }
     // best_anchor of the queued step k (wave-uniform k), exactly
@@ -542,7 +570,7 @@ struct DevWave {
         const u32 w = I.tw[valid ? hq >> tb : 0u];
         const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);
         const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
-        return __ballot(valid & ((z != 0) | (w == TW_OVERFLOW)));
+        return wballot(valid & ((z != 0) | (w == TW_OVERFLOW)));
     }
 
     // the close-seed probe of the tracking steps [i, i + nt): which steps have a candidate in their window
@@ -552,14 +580,204 @@ struct DevWave {
         const int W = imin(lit + nt - 1 + P.mrd, R.len - P.msl + 1 - r_end);
         if (W <= 0) return 0;
         const int w0 = imin(lane, W - 1), w1 = imin(lane + 64, W - 1);
+#ifdef LZANI_PRIO
+        __builtin_amdgcn_s_setprio(LZANI_PRIO);
+#endif
         qk = qkS[(u32)(i + lane)];
         rk0 = rkS[(u32)(r_end + w0)];
         rk1 = rkS[(u32)(r_end + w1)];
+#ifdef LZANI_PRIO
+        asm volatile("" : "+v"(qk), "+v"(rk0), "+v"(rk1));
+        __builtin_amdgcn_s_setprio(0);
+#endif
         qk = lane < nt ? qk : KM_INVALID;
         rk0 = lane < W ? rk0 : KM_INVALID;
         rk1 = lane + 64 < W ? rk1 : KM_INVALID;
         stamp(2);
-        return __ballot(seed_prefilter(rk0, rk1, qk));
+        return wballot(seed_prefilter(rk0, rk1, qk));
+    }
+
+
+    // a wave-uniform pointer the compiler keeps in vector registers, as a scalar pair (the base of a global_load)
+    static __device__ __forceinline__ const u32* uniform_ptr(const u32* p)
+    {
+        const u64 a = (u64)p;
+        const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)a), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(a >> 32));
+        return (const u32*)(((u64)hi << 32) | lo);
+    }
+    // The null chain (CHAIN = default LZ parameters, no alignment output): the cycle an unrelated pair spends four
+    // fifths of its events in -- tracking round over the 41 steps behind a match, no seed candidate, the next queued
+    // candidate is plain and distant, the region behind it is short and dropped, its record proves both extensions
+    // empty -- as ONE hand-scheduled loop in GCN, scalar state in fixed registers: ~45 scalar instructions per event
+    // against the ~140 the compiler spends on the same steps spread over find_event and PairMachine::run (phi copies
+    // and exit flags at every merge point).  Semantics: exactly find_event's common call followed
+    // by run()'s null event, repeated; it stops, with nothing half-done, at the first thing that is not that cycle:
+    //   returns 0   nothing in hand (queue empty or not covering the tracking steps, query or reference end near)
+    //   returns 1   the tracking round of step i is done: pre_seed / pre_rk0 / pre_rk1 / pre_qk, for find_event
+    //   returns 2   the next event is found but is not a null event: adv, bpos, blen (consumed from the queue)
+    // i, r_end, prev_rs, prev_re, pre_lit are the machine's; last_blen != 0 = null events were committed, the open
+    // region is the last one's match (cl = last_blen, clit = nl = 0).  Wait states of gfx950 are placed by hand
+    // (VALU-written mask -> VALU use: 2; lane select / VMEM base written by a VALU: the prologue is long enough).
+    __device__ __forceinline__ int null_chain(int& i, int& r_end, int& prev_rs, int& prev_re, int& pre_lit, int& last_blen,
+                                              int& adv, int& bpos, int& blen)
+    {
+        static_assert(!CHAIN || (FAST && BK), "the null chain reads the anchor queue");
+        enum { MQD = 40, MRD = 40, MSL = 7, REG = 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };    // params.h:34-48
+        const int ilim = imin(scan_pos, iend) - NT;             // the queue and the query cover the tracking steps of i <= ilim
+        const int rlim = R.len - MSL + 1 - WIN;                 // the seed window of r_end <= rlim is complete
+        const u32 ldsb = (u32)(size_t)bitmap;                   // LDS byte offset (low half of the flat address)
+        const u32 scrw = SEED_BM_WORDS + (u32)lane;             // a lane's own scratch word (see seed_prefilter)
+        const u32 zero = 0;
+        const u32* const qks = uniform_ptr(qkS);
+        const u32* const rks = uniform_ptr(rkS);
+        int code, ap, rec, t0, t1, t2, qh = q_head;
+        u64 m, seed;
+        u32 rk0, rk1, qk, a0, a1, aq, t, bq;
+#ifdef LZANI_CHAIN_STATS
+        int ncnt = 0;
+#define LZ_NC_COUNT "s_add_i32 %[ncnt], %[ncnt], 1\n\t"
+#define LZ_NC_COUNT_OPERAND [ncnt] "+s"(ncnt),
+#else
+#define LZ_NC_COUNT
+#define LZ_NC_COUNT_OPERAND
+#endif
+        asm volatile(
+            "s_mov_b32 %[code], 0\n\t"
+            "s_mov_b32 %[lastb], 0\n\t"
+            "s_nop 3\n"
+            "Lnc_top_%=:\n\t"
+            // the queue head: candidates the last match has passed go
+            "s_cmp_ge_i32 %[qh], %[qc]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "v_readlane_b32 %[t0], %[apos], %[qh]\n\t"
+            "s_cmp_ge_i32 %[t0], %[i]\n\t"
+            "s_cbranch_scc1 Lnc_nodrop_%=\n\t"
+            "v_cmp_le_i32_e32 vcc, %[qh], %[lane]\n\t"
+            "v_cmp_le_i32_e64 %[m], %[i], %[apos]\n\t"
+            "s_and_b64 %[m], %[m], vcc\n\t"
+            "s_ff1_i32_b64 %[qh], %[m]\n\t"
+            "s_min_u32 %[qh], %[qh], 64\n\t"
+            "s_cmp_ge_i32 %[qh], %[qc]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n"
+            "Lnc_nodrop_%=:\n\t"
+            "s_cmp_gt_i32 %[i], %[ilim]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_cmp_gt_i32 %[rend], %[rlim]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            // the tracking round (track_round + seed_prefilter): msl-mers of the 41 steps and of the 80 window positions
+            "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t"
+            "v_add_lshl_u32 %[a1], %[lane], %[rend], 2\n\t"
+            "v_or_b32_e32 %[aq], 64, %[lane]\n\t"
+            "v_min_u32_e32 %[aq], %[W1], %[aq]\n\t"
+            "v_add_lshl_u32 %[aq], %[aq], %[rend], 2\n\t"
+            "global_load_dword %[qk], %[a0], %[qks]\n\t"
+            "global_load_dword %[rk0], %[a1], %[rks]\n\t"
+            "global_load_dword %[rk1], %[aq], %[rks]\n\t"
+            "v_cmp_gt_u32_e32 vcc, %[NT], %[lane]\n\t"
+            "v_cmp_gt_u32_e64 %[m], %[NR1], %[lane]\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e32 %[qk], -1, %[qk], vcc\n\t"
+            "v_cndmask_b32_e64 %[rk1], -1, %[rk1], %[m]\n\t"
+            "v_cmp_eq_u32_e32 vcc, -1, %[rk0]\n\t"
+            "v_lshrrev_b32_e32 %[a0], 5, %[rk0]\n\t"
+            "v_lshlrev_b32_e64 %[t], %[rk0], 1\n\t"
+            "v_cndmask_b32_e32 %[a0], %[a0], %[scrw], vcc\n\t"
+            "v_cndmask_b32_e64 %[t], %[t], 0, vcc\n\t"
+            "v_cmp_eq_u32_e64 %[m], -1, %[rk1]\n\t"
+            "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t"
+            "ds_or_b32 %[a0], %[t]\n\t"
+            "v_lshrrev_b32_e32 %[a1], 5, %[rk1]\n\t"
+            "v_lshlrev_b32_e64 %[bq], %[rk1], 1\n\t"
+            "v_cndmask_b32_e64 %[a1], %[a1], %[scrw], %[m]\n\t"
+            "v_cndmask_b32_e64 %[bq], %[bq], 0, %[m]\n\t"
+            "v_cmp_ne_u32_e32 vcc, -1, %[qk]\n\t"
+            "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t"
+            "ds_or_b32 %[a1], %[bq]\n\t"
+            "v_lshrrev_b32_e32 %[aq], 5, %[qk]\n\t"
+            "v_lshlrev_b32_e64 %[t], %[qk], 1\n\t"
+            "v_cndmask_b32_e32 %[aq], %[scrw], %[aq], vcc\n\t"
+            "v_lshl_add_u32 %[aq], %[aq], 2, %[ldsb]\n\t"
+            "ds_read_b32 %[aq], %[aq]\n\t"
+            "ds_write_b32 %[a0], %[zero]\n\t"
+            "ds_write_b32 %[a1], %[zero]\n\t"
+            "s_waitcnt lgkmcnt(2)\n\t"
+            "v_and_b32_e32 %[aq], %[aq], %[t]\n\t"
+            "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t"
+            "s_mov_b32 %[code], 1\n\t"
+            "s_and_b64 %[seed], %[m], vcc\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            // no seed candidate among the tracking steps: the next queued candidate, if it is plain
+            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
+            "v_readlane_b32 %[ap], %[apos], %[qh]\n\t"
+            "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
+            "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
+            "s_cmp_lt_i32 %[blen], 1\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_mov_b32 %[code], 2\n\t"
+            // the event: close (a tracking step near the predicted position) = not ours
+            "s_sub_i32 %[t0], %[ap], %[i]\n\t"
+            "s_cmp_gt_i32 %[t0], %[MQD]\n\t"
+            "s_cbranch_scc1 Lnc_distant_%=\n\t"
+            "s_add_i32 %[t1], %[rend], %[t0]\n\t"
+            "s_sub_i32 %[t1], %[bpos], %[t1]\n\t"
+            "s_abs_i32 %[t1], %[t1]\n\t"
+            "s_cmp_le_i32 %[t1], %[MRD]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n"
+            "Lnc_distant_%=:\n\t"
+            // distant: the open region must be a short one (dropped), the record must prove both extensions empty
+            "s_cmp_lt_i32 %[prs], 0\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_sub_i32 %[t1], %[pre], %[prs]\n\t"
+            "s_cmp_ge_i32 %[t1], %[REG]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_bitcmp0_b32 %[rec], 31\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
+            "s_add_i32 %[t1], %[t1], %[plit]\n\t"           // avail
+            "s_min_i32 %[t2], %[t1], %[ap]\n\t"
+            "s_min_i32 %[t2], %[t2], %[bpos]\n\t"           // reach
+            "s_cmp_lt_i32 %[t2], 1\n\t"
+            "s_cbranch_scc1 Lnc_commit_%=\n\t"
+            "s_min_i32 %[t0], %[t2], %[AW]\n\t"
+            "s_bfm_b32 %[t0], %[t0], 0\n\t"
+            "s_and_b32 %[t0], %[t0], %[rec]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_cmp_le_i32 %[t2], %[AW]\n\t"
+            "s_cbranch_scc1 Lnc_commit_%=\n\t"
+            "s_bitcmp0_b32 %[rec], 30\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n"
+            "Lnc_commit_%=:\n\t"
+            "s_mov_b32 %[plit], %[t1]\n\t"
+            "s_mov_b32 %[prs], %[ap]\n\t"
+            "s_mov_b32 %[lastb], %[blen]\n\t"
+            "s_add_i32 %[i], %[ap], %[blen]\n\t"
+            "s_add_i32 %[rend], %[bpos], %[blen]\n\t"
+            "s_mov_b32 %[pre], %[i]\n\t"
+            "s_add_i32 %[qh], %[qh], 1\n\t"
+            "s_mov_b32 %[code], 0\n\t"
+            LZ_NC_COUNT
+            "s_branch Lnc_top_%=\n"
+            "Lnc_end_%=:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_nop 4"
+            : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit),
+              [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_blen), [rec] "=&s"(rec),
+              [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [m] "=&s"(m), [seed] "=&s"(seed),
+              [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq)
+            : [qc] "s"(q_cnt), [ilim] "s"(ilim), [rlim] "s"(rlim), [qks] "s"(qks), [rks] "s"(rks),
+              [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), [scrw] "v"(scrw),
+              [ldsb] "v"(ldsb), [zero] "v"(zero),
+              [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [W1] "n"(WIN - 1), [NR1] "n"(WIN - 64)
+            : "vcc", "scc", "memory");
+        q_head = qh;
+        pre_round = code == 1;
+        pre_seed = seed; pre_rk0 = rk0; pre_rk1 = rk1; pre_qk = qk;
+        if (code == 2) { adv = ap - i; last_src = q_head++; }
+#ifdef LZANI_CHAIN_STATS
+        st[0] += 1; st[1] += ncnt; st[2] += code == 0; st[3] += code == 1 && seed != 0; st[4] += code == 1 && seed == 0; st[5] += code == 2;
+#endif
+        return code;
     }
 
     __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit, int& adv, int& bpos, int& blen)
@@ -574,7 +792,10 @@ struct DevWave {
         bool round_done = !trk;
         u32 rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
         u64 seedmask = 0;
-        if (__builtin_expect(!refill_now, 1)) {
+        const bool pre = CHAIN && pre_round;                         // null_chain has done this call's tracking round (and found
+        pre_round = false;                                           // a seed candidate or a candidate that is not plain)
+        if (pre) { seedmask = pre_seed; rk0 = pre_rk0; rk1 = pre_rk1; qk = pre_qk; round_done = true; }
+        else if (__builtin_expect(!refill_now, 1)) {
             // The common call, straight down, no loop: one round over the tracking steps (close seeds as in
             // find_event_round) and, when none of them has a seed candidate (four rounds out of five of an unrelated
             // pair), the next queued candidate.  A tracking step can then only hit through its anchor, which wins the
@@ -717,8 +938,8 @@ struct DevWave {
         bool b, q;
         ext_lane(prevB, B, lane, n, P.aw, P.am, P.ar, b, q);
         ExtMasks m;
-        m.brk = __ballot(b);
-        m.qual = __ballot(q);
+        m.brk = wballot(b);
+        m.qual = wballot(q);
         return m;
     }
     __device__ __forceinline__ int best_split(u64 Lm, u64 Rm, int to_scan) const
@@ -864,14 +1085,15 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
         iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
         const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
-        DevWave<FAST, BK, JOIN> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
+        constexpr bool CHAIN = FAST && BK && DEFP && !ALN;
+        DevWave<FAST, BK, JOIN, CHAIN> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                         qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
                         lds,
                         FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
                         FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
         w.iend = D - Pk.msl;
         w.cand_bits = cand_bits;
-        PairMachine<DevWave<FAST, BK, JOIN>, ALN> m(w, Pk, T, D);
+        PairMachine<DevWave<FAST, BK, JOIN, CHAIN>, ALN> m(w, Pk, T, D);
         int res[3];
 #ifdef LZANI_STAMPS
         for (int k = 0; k < 8; ++k) w.acc[k] = 0;
@@ -883,6 +1105,9 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
         if (!JOIN)
 #endif
         m.run(res);
+#ifdef LZANI_CHAIN_STATS
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[k], lane == 0 ? (unsigned long long)w.st[k] : 0ULL);
+#endif
 #ifdef LZANI_STAMPS
         w.stamp(0);
         for (int k = 0; k < 8; ++k) atomicAdd(&g_stamp_acc[k], lane == 0 ? w.acc[k] : 0ULL);      // (no lane-dependent branch in this loop)
