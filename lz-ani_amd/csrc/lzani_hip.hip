@@ -70,6 +70,9 @@ struct lzani_ctx {
     bool build_attr_set = false;
     u32* d_tw = nullptr;          // tag words of the bucket tables (tag bits <= 7)
     u64 tw_stride = 0;
+    u32* d_fl = nullptr;          // presence filters (probe form with tag words), or one all-ones word
+    u64 fl_stride = 0;            // words per slot; 0 = no filter (d_fl = the all-ones word)
+    u32 fmask = 31;
     u32 slots = 0;
     u32 batches_last_run = 0;
     // join form of candidate detection (long genomes): per-genome k-mer lists sorted by bucket
@@ -91,6 +94,8 @@ struct lzani_ctx {
     u32 max_slots = 65535;        // gridDim.y limit; LZANI_MAX_SLOTS lowers it (tests force the multi-batch path)
     u64 dir_stride = 0, ent_stride = 0;
     unsigned long long* d_cursor = nullptr;
+    u32* d_blkctr = nullptr;      // k_pairs_blk: one pair counter per block
+    int blk_fold = -1;            // k_pairs_blk: LDS filter = global filter folded 2^blk_fold times (-1: not decided yet)
 
     lzani_timing tm{};
 
@@ -146,7 +151,8 @@ void free_genomes(lzani_ctx* c)
 }
 void free_slabs(lzani_ctx* c)
 {
-    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_bk); hipFree(c->d_tw); hipFree(c->d_status);
+    hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_bk); hipFree(c->d_tw); hipFree(c->d_fl); hipFree(c->d_status);
+    c->d_fl = nullptr;
     hipFree(c->d_ikeys_in); hipFree(c->d_ikeys); hipFree(c->d_icnt); hipFree(c->d_ibase);
     c->d_ikeys_in = c->d_ikeys = nullptr; c->d_icnt = nullptr; c->d_ibase = nullptr;
     c->d_dirz = c->d_ent = c->d_bk = c->d_tw = c->d_status = nullptr; c->slots = 0;
@@ -185,6 +191,18 @@ void choose_index_form(lzani_ctx* c)
         const char* ns = getenv("LZANI_NO_SORT_INDEX");
         c->sort_build = c->d_kmL && c->geo.dirbits >= (sm ? atoi(sm) : 20) && c->geo.kb + c->geo.posbits <= 60 && !(ns && *ns == '1');
     }
+    // Presence filter in front of the tag-word probes (probe form only; k_pairs_blk keeps the reference's in LDS): ~3 bits
+    // per text position, at most 2^18 bits (genomes up to ~128 kbp); beyond, one all-ones word passes everything
+    {
+        const char* nf = getenv("LZANI_NO_FILTER");
+        const char* fx = getenv("LZANI_FILTER_MAX_BITS");
+        const int fmax = fx ? atoi(fx) : 18;                          // 2^18 bits = 32 KB of LDS per block of 16 waves
+        const int fbits = std::min(ceil_log2((u64)std::max(c->Tmax, 1024)) + 1, fmax);
+        const bool on = c->tw_stride && !c->join_mode && ceil_log2((u64)std::max(c->Tmax, 1024)) <= fmax && !(nf && *nf == '1');
+        c->fl_stride = on ? ((u64)1 << fbits) / 32 : 0;
+        c->blk_fold = -1;
+        c->fmask = on ? (u32)((1u << fbits) - 1u) : 31u;
+    }
     const char* ms = getenv("LZANI_MAX_SLOTS");
     c->max_slots = ms && atoi(ms) > 0 ? (u32)std::min(65535, atoi(ms)) : 65535u;
     if (c->sort_build)                                  // the slot number shares the 64-bit key with hash and position
@@ -193,7 +211,7 @@ void choose_index_form(lzani_ctx* c)
 
 int ensure_slabs(lzani_ctx* c, u32 want_rows)
 {
-    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride) + (c->sort_build ? (size_t)16 * c->Tmax + 16 : 0);
+    size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride) + (c->sort_build ? (size_t)16 * c->Tmax + 16 : 0);
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
     size_t have = c->slots * per_slot;
@@ -205,6 +223,10 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
     HIPCHK(c, hipMalloc(&c->d_ent, (size_t)slots * c->ent_stride * 4));
     if (c->bk_stride) HIPCHK(c, hipMalloc(&c->d_bk, (size_t)slots * c->bk_stride * 4));
     if (c->tw_stride) HIPCHK(c, hipMalloc(&c->d_tw, (size_t)slots * c->tw_stride * 4));
+    if (c->tw_stride) {
+        HIPCHK(c, hipMalloc(&c->d_fl, std::max<size_t>((size_t)slots * c->fl_stride * 4, 4)));
+        if (!c->fl_stride) HIPCHK(c, hipMemset(c->d_fl, 0xFF, 4));
+    }
     HIPCHK(c, hipMalloc(&c->d_status, (size_t)slots * 4));
     if (c->sort_build) {
         HIPCHK(c, hipMalloc(&c->d_ikeys_in, (size_t)slots * c->Tmax * 8));
@@ -319,6 +341,12 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
         c->kmers_ready = true;
         c->tm.index_launches += 1;
         if (c->join_mode) { int rc = build_join_lists(c); if (rc) return rc; }
+    }
+    if (c->fl_stride) {
+        HIPCHK(c, hipMemsetAsync(c->d_fl, 0, (size_t)rows * c->fl_stride * 4, c->stream));
+        hipLaunchKernelGGL(k_idx_filter, dim3((u32)std::min<u64>(((u64)c->Tmax + 255) / 256, 64), rows), dim3(256), 0, c->stream,
+                           ia, c->d_fl, c->fl_stride, c->fmask, c->Tmax);
+        c->tm.index_launches += 1;
     }
     if (c->sort_build) {
         // keys -> radix sort (groups of slots below 2^30 keys) -> the tables in one streaming pass
@@ -503,6 +531,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.dir_stride = c->dir_stride; pa.ent_stride = c->ent_stride;
             pa.bk = c->d_bk; pa.bk_stride = c->bk_stride;
             pa.tw = c->d_tw; pa.tw_stride = c->tw_stride;
+            pa.fl = c->d_fl; pa.fl_stride = c->fl_stride; pa.fmask = c->fmask;
             pa.ref_ids = d_ref + k0; pa.row_off = d_off + k0; pa.query_ids = d_q;
             pa.out = d_out; pa.cursor = c->d_cursor;
             pa.qorder = d_qorder + k0; pa.qcum = d_qcum + k0 + b;
@@ -527,6 +556,29 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (nf) LZ_PAIRS_JOIN(true, false);
                 else if (defp) LZ_PAIRS_JOIN(false, true);
                 else LZ_PAIRS_JOIN(false, false);
+            } else if (tw && c->fl_stride && (e1 - e0) / rows >= 128 && !getenv("LZANI_NO_BLOCK_KERNEL")) {
+                // probe form, rows of hundreds of pairs: blocks of 16 waves with the reference's presence filter in LDS
+                if (!c->d_blkctr) HIPCHK(c, hipMalloc(&c->d_blkctr, (size_t)c->n_cus * 2 * 4));
+                const void* kf = nf ? (defp ? (const void*)k_pairs_blk<true, true> : (const void*)k_pairs_blk<true, false>)
+                                    : (defp ? (const void*)k_pairs_blk<false, true> : (const void*)k_pairs_blk<false, false>);
+                if (c->blk_fold < 0) {              // the largest LDS copy of the filter that leaves two blocks per CU
+                    for (int fold = 0; fold <= 4 && c->blk_fold < 0; ++fold) {
+                        const size_t lds = (size_t)(BLK_WAVES * SEED_LDS_WORDS + std::max<u64>(c->fl_stride >> fold, 1)) * 4;
+                        if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); continue; }
+                        int nb = 0;
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf, 64 * BLK_WAVES, lds) == hipSuccess && nb >= 2) c->blk_fold = fold;
+                    }
+                    if (c->blk_fold < 0) return fail(c, LZANI_ERR_DEVICE, "k_pairs_blk: no LDS configuration with two blocks per CU");
+                }
+                const u32 fw = (u32)std::max<u64>(c->fl_stride >> c->blk_fold, 1);
+                const size_t lds = (size_t)(BLK_WAVES * SEED_LDS_WORDS + fw) * 4;
+                HIPCHK(c, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                pa.fmask = c->fmask >> c->blk_fold;
+                const dim3 gb((u32)std::min<u64>((waves + BLK_CHUNK - 1) / BLK_CHUNK, (u64)c->n_cus * 2)), bb(64 * BLK_WAVES);
+                if (nf && defp) hipLaunchKernelGGL((k_pairs_blk<true, true>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
+                else if (nf) hipLaunchKernelGGL((k_pairs_blk<true, false>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
+                else if (defp) hipLaunchKernelGGL((k_pairs_blk<false, true>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
+                else hipLaunchKernelGGL((k_pairs_blk<false, false>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
             } else if (tw) {
                 if (nf && defp) LZ_PAIRS(true, true, true, false, true);
                 else if (nf) LZ_PAIRS(true, true, false, false, true);
@@ -639,6 +691,7 @@ void lzani_destroy(lzani_ctx* c)
     free_genomes(c);
     free_slabs(c);
     hipFree(c->d_cursor);
+    hipFree(c->d_blkctr);
     for (auto& e : c->events) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -815,7 +868,7 @@ int lzani_get_layout(const lzani_ctx* c, lzani_layout_info* o)
     o->bucket_table = c->bk_stride != 0; o->tag_words = c->tw_stride != 0;
     o->n_free = c->all_nfree;
     o->slots = c->slots; o->batches_last_run = c->batches_last_run;
-    o->bytes_per_slot = 4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride);
+    o->bytes_per_slot = 4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride);
     o->bytes_genomes = c->total_nm * (16 + 8) + (c->d_kmL ? c->total_nm * 64 * 8 : 0);
     o->join_lists = c->join_mode; o->reserved = 0;
     return LZANI_OK;

@@ -24,7 +24,7 @@ enum { AQ_NONE = 0x7FFFFFFF };
 // the wave's vote as the compare result itself (HIP's __ballot goes through an int: v_cndmask 0/1 + v_cmp_ne per vote)
 __device__ __forceinline__ u64 wballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
-template <bool FAST, bool BK = false, bool JOIN = false, bool CHAIN = false>
+template <bool FAST, bool BK = false, bool JOIN = false, bool CHAIN = false, bool LFLT = false>
 struct DevWave {
     static constexpr bool NULL_CHAIN = CHAIN;
     const Params& P;
@@ -58,6 +58,9 @@ struct DevWave {
     bool pre_round = false;
     u64 pre_seed = 0;
     u32 pre_rk0 = KM_INVALID, pre_rk1 = KM_INVALID, pre_qk = KM_INVALID;
+    // LFLT: the block's copy, in LDS, of the presence filter of the reference (k_idx_filter): bit (h & fmask)
+    const u32* flt = nullptr;
+    u32 fmask = 31;
     __device__ __forceinline__ void emit_region(const RegionCoords& c) const
     {
         // One slot per wave, reserved by ONE lane and without a lane-dependent branch (see the note at the ticket fetch:
@@ -428,9 +431,19 @@ struct DevWave {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 valid[c] = (scan_pos + 64 * c + lane < iend) & (hq[c] != KM_INVALID);
+                // presence filter (LDS): no such k-mer in the reference = no probe
+                if (LFLT) valid[c] &= (bool)((flt[(hq[c] & fmask) >> 5] >> (hq[c] & 31u)) & 1u);
                 w[c] = I.tw[valid[c] ? hq[c] >> tb : 0u];
             }
             asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+#ifdef LZANI_PROBE2X                      // diagnostic build: every tag-word probe twice (a second, unrelated line)
+            {
+                u32 d[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[c] = I.tw[valid[c] ? ((hq[c] * 0x9E3779B1u) >> (32 - I.dirbits)) : 0u];
+                asm volatile("" :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+            }
+#endif
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (scan_pos >= iend || ncand >= AQ_CAP) break;               // wave-uniform
@@ -675,8 +688,44 @@ struct DevWave {
             "global_load_dword %[rk1], %[aq], %[rks]\n\t"
             "v_cmp_gt_u32_e32 vcc, %[NT], %[lane]\n\t"
             "v_cmp_gt_u32_e64 %[m], %[NR1], %[lane]\n\t"
+            // While the loads fly: the next queued candidate and, should the round find no seed candidate, whether it is
+            // a null event (t2 = 1): plain, distant, the open region short (dropped), both extensions empty by the record
+            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
+            "v_readlane_b32 %[ap], %[apos], %[qh]\n\t"
+            "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
+            "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
+            "s_mov_b32 %[t2], 0\n\t"
+            "s_cmp_lt_i32 %[blen], 1\n\t"
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_sub_i32 %[t0], %[ap], %[i]\n\t"
+            "s_cmp_le_i32 %[t0], %[MQD]\n\t"
+            "s_cbranch_scc1 Lnc_close_%=\n"
+            "Lnc_distant_%=:\n\t"
+            "s_cmp_lt_i32 %[prs], 0\n\t"
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_sub_i32 %[t1], %[pre], %[prs]\n\t"
+            "s_cmp_ge_i32 %[t1], %[REG]\n\t"
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_bitcmp0_b32 %[rec], 31\n\t"
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
+            "s_add_i32 %[t1], %[t1], %[plit]\n\t"           // avail
+            "s_min_i32 %[t0], %[t1], %[ap]\n\t"
+            "s_min_i32 %[t0], %[t0], %[bpos]\n\t"           // reach
+            "s_cmp_lt_i32 %[t0], 1\n\t"
+            "s_cbranch_scc1 Lnc_ok_%=\n\t"
+            "s_min_i32 %[code], %[t0], %[AW]\n\t"
+            "s_bfm_b32 %[code], %[code], 0\n\t"
+            "s_and_b32 %[code], %[code], %[rec]\n\t"
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_cmp_le_i32 %[t0], %[AW]\n\t"
+            "s_cbranch_scc1 Lnc_ok_%=\n\t"
+            "s_bitcmp0_b32 %[rec], 30\n\t"
+            "s_cbranch_scc1 Lnc_chk_%=\n"
+            "Lnc_ok_%=:\n\t"
+            "s_mov_b32 %[t2], 1\n"
+            "Lnc_chk_%=:\n\t"
             "s_waitcnt vmcnt(0)\n\t"
-            "s_nop 0\n\t"
             "v_cndmask_b32_e32 %[qk], -1, %[qk], vcc\n\t"
             "v_cndmask_b32_e64 %[rk1], -1, %[rk1], %[m]\n\t"
             "v_cmp_eq_u32_e32 vcc, -1, %[rk0]\n\t"
@@ -706,48 +755,13 @@ struct DevWave {
             "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t"
             "s_mov_b32 %[code], 1\n\t"
             "s_and_b64 %[seed], %[m], vcc\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            // no seed candidate among the tracking steps: the next queued candidate, if it is plain
-            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
-            "v_readlane_b32 %[ap], %[apos], %[qh]\n\t"
-            "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
-            "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // a seed candidate: the round is done, the rest is find_event's
             "s_cmp_lt_i32 %[blen], 1\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the candidate is not plain: likewise
             "s_mov_b32 %[code], 2\n\t"
-            // the event: close (a tracking step near the predicted position) = not ours
-            "s_sub_i32 %[t0], %[ap], %[i]\n\t"
-            "s_cmp_gt_i32 %[t0], %[MQD]\n\t"
-            "s_cbranch_scc1 Lnc_distant_%=\n\t"
-            "s_add_i32 %[t1], %[rend], %[t0]\n\t"
-            "s_sub_i32 %[t1], %[bpos], %[t1]\n\t"
-            "s_abs_i32 %[t1], %[t1]\n\t"
-            "s_cmp_le_i32 %[t1], %[MRD]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n"
-            "Lnc_distant_%=:\n\t"
-            // distant: the open region must be a short one (dropped), the record must prove both extensions empty
-            "s_cmp_lt_i32 %[prs], 0\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_sub_i32 %[t1], %[pre], %[prs]\n\t"
-            "s_cmp_ge_i32 %[t1], %[REG]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_bitcmp0_b32 %[rec], 31\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
-            "s_add_i32 %[t1], %[t1], %[plit]\n\t"           // avail
-            "s_min_i32 %[t2], %[t1], %[ap]\n\t"
-            "s_min_i32 %[t2], %[t2], %[bpos]\n\t"           // reach
-            "s_cmp_lt_i32 %[t2], 1\n\t"
-            "s_cbranch_scc1 Lnc_commit_%=\n\t"
-            "s_min_i32 %[t0], %[t2], %[AW]\n\t"
-            "s_bfm_b32 %[t0], %[t0], 0\n\t"
-            "s_and_b32 %[t0], %[t0], %[rec]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_cmp_le_i32 %[t2], %[AW]\n\t"
-            "s_cbranch_scc1 Lnc_commit_%=\n\t"
-            "s_bitcmp0_b32 %[rec], 30\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n"
-            "Lnc_commit_%=:\n\t"
+            "s_cmp_eq_u32 %[t2], 0\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the event is found but is not a null event
+            // the null event
             "s_mov_b32 %[plit], %[t1]\n\t"
             "s_mov_b32 %[prs], %[ap]\n\t"
             "s_mov_b32 %[lastb], %[blen]\n\t"
@@ -758,6 +772,13 @@ struct DevWave {
             "s_mov_b32 %[code], 0\n\t"
             LZ_NC_COUNT
             "s_branch Lnc_top_%=\n"
+            "Lnc_close_%=:\n\t"                             // a tracking step: close to the predicted position = not ours
+            "s_add_i32 %[t1], %[rend], %[t0]\n\t"
+            "s_sub_i32 %[t1], %[bpos], %[t1]\n\t"
+            "s_abs_i32 %[t1], %[t1]\n\t"
+            "s_cmp_le_i32 %[t1], %[MRD]\n\t"
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_branch Lnc_distant_%=\n"
             "Lnc_end_%=:\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_nop 4"
@@ -997,6 +1018,9 @@ struct PairArgs {
     u64 bk_stride;
     const u32* tw;           // tag words (one per bucket) or nullptr
     u64 tw_stride;
+    const u32* fl;           // presence filters (probe form with tag words; fl_stride 0 = one all-ones word for all)
+    u64 fl_stride;
+    u32 fmask;
     const u32* ref_ids;      // device, batch-relative rows
     const u64* row_off;      // device, batch-relative rows (+1), absolute pair offsets
     const u32* query_ids;    // device, absolute pair offsets, or nullptr for dense rows
@@ -1033,10 +1057,84 @@ __device__ __forceinline__ u32 xcc_id()
 // defaults (params.h:34-48), folded into the code as constants.
 // ALN = also emit the regions of every pair (--out-alignment).
 // JOIN = candidates by a join with sorted k-mer lists (long genomes; needs FAST and BK).
+// One pair: row `lo` of the batch's queue order, its j-th query.  `flt` = the block's LDS copy of the reference's
+// presence filter (LFLT instantiations).
+template <bool FAST, bool NFREE, bool DEFP, bool ALN, bool BK, bool JOIN, bool LFLT>
+__device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int lane, u32* lds, const u32* flt)
+{
+    const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
+    const u32 slot = a.qorder[lo];
+    const u32 r = a.ref_ids[slot];
+    const u64 e = a.row_off[slot] + j;
+    const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
+
+    unsigned long long* cand_bits = nullptr;
+    if (JOIN) {
+        cand_bits = a.cbits + (u64)(blockIdx.x * 4 + (threadIdx.x >> 6)) * a.cbits_stride;
+        join_candidates(a.tw + slot * a.tw_stride, a.geo.kb, a.geo.dirbits, a.geo.posbits, a.geo.tagmask,
+                        a.skeys + a.soff[q], a.scnt[q], cand_bits, ((a.G.L[q] + (DEFP ? 40 : a.P.mrd)) >> 6) + 8, lane);
+    }
+    const int Lr = a.G.L[r], Lq = a.G.L[q];
+    const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
+    const int T = ref_text_len(Lr, Pk.mrd), D = Lq + Pk.mrd;
+    IndexView iv;
+    iv.dirz = a.dirz + slot * a.dir_stride;
+    iv.ent = a.ent + slot * a.ent_stride;
+    iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
+    iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
+    iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
+    const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
+    constexpr bool CHAIN = FAST && BK && DEFP && !ALN;
+    DevWave<FAST, BK, JOIN, CHAIN, LFLT> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
+                    qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
+                    lds,
+                    FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
+                    FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
+    w.iend = D - Pk.msl;
+    w.cand_bits = cand_bits;
+    w.flt = flt; w.fmask = a.fmask;                      // (the block kernel passes the mask of its LDS copy)
+    PairMachine<DevWave<FAST, BK, JOIN, CHAIN, LFLT>, ALN> m(w, Pk, T, D);
+    int res[3];
+#ifdef LZANI_STAMPS
+    for (int k = 0; k < 8; ++k) w.acc[k] = 0;
+    w.cur = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.t0) :: "memory");
+#endif
+#if defined(LZANI_EXP) && LZANI_EXP == 3                      // diagnostic build: the join alone, no scan
+    res[0] = res[1] = res[2] = 0;
+    if (!JOIN)
+#endif
+    m.run(res);
+#ifdef LZANI_CHAIN_STATS
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[k], lane == 0 ? (unsigned long long)w.st[k] : 0ULL);
+#endif
+#ifdef LZANI_STAMPS
+    w.stamp(0);
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_stamp_acc[k], lane == 0 ? w.acc[k] : 0ULL);      // (no lane-dependent branch in this loop)
+#endif
+    int* o = a.out + 3 * e;          // every lane stores the same wave-uniform values
+    o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+}
+
+// row of the queue's pair ticket tk (absolute in qcum): the last row of [rb, re) with qcum[row] <= tk
+__device__ __forceinline__ u32 row_of_ticket(const u64* __restrict__ qcum, u32 rb, u32 re, u64 tk)
+{
+    u32 lo = rb, hi = re;
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (qcum[mid] <= tk) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Instantiations: FAST = per-genome k-mer words exist (mal, msl <= 15); NFREE = no genome of the
+// context holds an N (the N mask is never consulted); DEFP = the LZ parameters are the reference's
+// defaults (params.h:34-48), folded into the code as constants.
+// ALN = also emit the regions of every pair (--out-alignment).
+// JOIN = candidates by a join with sorted k-mer lists (long genomes; needs FAST and BK).
 template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false, bool JOIN = false>
 __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 {
-    const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
     const int lane = threadIdx.x & 63;
     __shared__ u32 s_seed[4][SEED_LDS_WORDS];
     u32* const lds = s_seed[threadIdx.x >> 6];
@@ -1058,62 +1156,72 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
             qx = (qx + 1) % NQUEUES;
             continue;
         }
-        u32 lo = rb, hi = re;                     // last row of the queue with qcum[row] <= tk
-        while (hi - lo > 1) {
-            u32 mid = (lo + hi) >> 1;
-            if (a.qcum[mid] <= tk) lo = mid; else hi = mid;
-        }
-        const u32 slot = a.qorder[lo];
-        const u32 r = a.ref_ids[slot];
-        const u32 j = (u32)(tk - a.qcum[lo]);
-        const u64 e = a.row_off[slot] + j;
-        const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
+        const u32 lo = row_of_ticket(a.qcum, rb, re, tk);
+        pair_body<FAST, NFREE, DEFP, ALN, BK, JOIN, false>(a, lo, (u32)(tk - a.qcum[lo]), lane, lds, nullptr);
+    }
+}
 
-        unsigned long long* cand_bits = nullptr;
-        if (JOIN) {
-            cand_bits = a.cbits + (u64)(blockIdx.x * 4 + (threadIdx.x >> 6)) * a.cbits_stride;
-            join_candidates(a.tw + slot * a.tw_stride, a.geo.kb, a.geo.dirbits, a.geo.posbits, a.geo.tagmask,
-                            a.skeys + a.soff[q], a.scnt[q], cand_bits, ((a.G.L[q] + (DEFP ? 40 : a.P.mrd)) >> 6) + 8, lane);
+// The same pairs by BLOCKS of 16 waves that stay on one reference at a time (probe form with tag words, rows of
+// hundreds of pairs): a block draws a chunk of BLK_CHUNK pair tickets from its XCD's queue and walks it row by row;
+// per row segment it copies the reference's presence filter (k_idx_filter) into LDS, its waves pull the segment's
+// pairs one by one, and a barrier ends the segment.  The filter answers "no such mal-mer in the reference" for three
+// query positions out of four without leaving the CU: the tag-word probes -- random 4-byte reads that cost a
+// 128-byte L2 line each, the traffic that bounds the viral pair kernel at the L2 -- are made for the rest only.
+// Every barrier is reached by all 16 waves the same number of times: chunk and segment bounds are block-uniform.
+enum { BLK_WAVES = 16, BLK_CHUNK = 256 };
+template <bool NFREE, bool DEFP>
+__global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32 fwords, u32 fold, u32* __restrict__ blkctr)
+{
+    extern __shared__ u32 s_dyn[];                 // BLK_WAVES x SEED_LDS_WORDS, then the filter (fwords)
+    const int lane = threadIdx.x & 63;
+    u32* const lds = s_dyn + (threadIdx.x >> 6) * SEED_LDS_WORDS;
+    u32* const flt = s_dyn + BLK_WAVES * SEED_LDS_WORDS;
+    u32* const ctl = s_dyn + SEED_BM_WORDS;        // two words in wave 0's candidate buffer: dead while the block is between segments
+    for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[k] = 0;
+    u32 qx = xcc_id() % NQUEUES, dry = 0;
+    for (;;) {
+        __syncthreads();                           // (ctl is free: nobody is inside a pair)
+        if (threadIdx.x == 0) {
+            const unsigned long long t = atomicAdd(&a.cursor[qx], (unsigned long long)BLK_CHUNK);
+            ctl[0] = (u32)t; ctl[1] = (u32)(t >> 32);
         }
-        const int Lr = a.G.L[r], Lq = a.G.L[q];
-        const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
-        const int T = ref_text_len(Lr, Pk.mrd), D = Lq + Pk.mrd;
-        IndexView iv;
-        iv.dirz = a.dirz + slot * a.dir_stride;
-        iv.ent = a.ent + slot * a.ent_stride;
-        iv.kb = a.geo.kb; iv.dirbits = a.geo.dirbits; iv.posbits = a.geo.posbits; iv.tagmask = a.geo.tagmask;
-        iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
-        iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
-        const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
-        constexpr bool CHAIN = FAST && BK && DEFP && !ALN;
-        DevWave<FAST, BK, JOIN, CHAIN> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
-                        qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
-                        lds,
-                        FAST ? a.G.kmS + 64 * ro : nullptr, FAST ? a.G.kmL + 64 * qo : nullptr,
-                        FAST ? a.G.kmS + 64 * qo : nullptr, a.reg_out, a.reg_count, a.reg_cap, e};
-        w.iend = D - Pk.msl;
-        w.cand_bits = cand_bits;
-        PairMachine<DevWave<FAST, BK, JOIN, CHAIN>, ALN> m(w, Pk, T, D);
-        int res[3];
-#ifdef LZANI_STAMPS
-        for (int k = 0; k < 8; ++k) w.acc[k] = 0;
-        w.cur = 0;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.t0) :: "memory");
-#endif
-#if defined(LZANI_EXP) && LZANI_EXP == 3                      // diagnostic build: the join alone, no scan
-        res[0] = res[1] = res[2] = 0;
-        if (!JOIN)
-#endif
-        m.run(res);
-#ifdef LZANI_CHAIN_STATS
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[k], lane == 0 ? (unsigned long long)w.st[k] : 0ULL);
-#endif
-#ifdef LZANI_STAMPS
-        w.stamp(0);
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_stamp_acc[k], lane == 0 ? w.acc[k] : 0ULL);      // (no lane-dependent branch in this loop)
-#endif
-        int* o = a.out + 3 * e;          // every lane stores the same wave-uniform values
-        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+        __syncthreads();
+        const u64 t0 = ((u64)ctl[1] << 32) | ctl[0];
+        const u32 rb = a.qb[qx], re = a.qb[qx + 1];
+        const u64 base = a.qcum[rb], total = a.qcum[re] - base;
+        if (t0 >= total) {                         // this queue is dry (block-uniform): move on, leave after NQUEUES dry queues
+            if (++dry >= NQUEUES) break;
+            qx = (qx + 1) % NQUEUES;
+            continue;
+        }
+        const u64 t1 = t0 + BLK_CHUNK < total ? t0 + BLK_CHUNK : total;
+        u32 lo = row_of_ticket(a.qcum, rb, re, base + t0);
+        for (u64 cur = t0; cur < t1; ++lo) {       // the rows of the chunk (rows without pairs fall through)
+            const u64 row_end = a.qcum[lo + 1] - base;
+            const u64 seg_end = row_end < t1 ? row_end : t1;
+            if (seg_end <= cur) continue;
+            const u32 slot = a.qorder[lo];
+            const u32* const gf = a.fl + (u64)slot * a.fl_stride;
+            // (a filter of fwords << fold words folded onto fwords: bit b of the copy = OR of the bits b + i * 32 * fwords)
+            for (u32 k = threadIdx.x; k < fwords; k += 64 * BLK_WAVES) {
+                u32 v = gf[k];
+                for (u32 i = 1; i < (1u << fold); ++i) v |= gf[k + i * fwords];
+                flt[k] = v;
+            }
+            if (threadIdx.x == 0) { blkctr[blockIdx.x] = 0; __threadfence(); }
+            __syncthreads();
+            const u32 n_seg = (u32)(seg_end - cur);
+            const u32 j0 = (u32)(base + cur - a.qcum[lo]);
+            for (;;) {
+                u32 k = 0;
+                if (lane == 0) k = atomicAdd(&blkctr[blockIdx.x], 1u);
+                k = __builtin_amdgcn_readfirstlane(k);
+                if (k >= n_seg) break;
+                pair_body<true, NFREE, DEFP, false, true, false, true>(a, lo, j0 + k, lane, lds, flt);
+            }
+            __syncthreads();                       // the filter and the counter are free again
+            cur = seg_end;
+        }
     }
 }
 
