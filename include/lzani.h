@@ -128,7 +128,8 @@ typedef struct lzani_layout_info {
     uint64_t bytes_per_slot;                /* HBM bytes of one index slab                                           */
     uint64_t bytes_genomes;                 /* HBM bytes of packed texts + N masks + k-mer words                     */
     int32_t  join_lists;                    /* 1: candidates come from a join with per-genome sorted k-mer lists (long genomes) */
-    int32_t  reserved;
+    int32_t  block_launches;                /* pair-kernel launches of the last run by blocks of 16 waves with the
+                                             * reference's presence filter in LDS (probe form, rows of >= 128 pairs) */
 } lzani_layout_info;
 int lzani_get_layout(const lzani_ctx *ctx, lzani_layout_info *info);
 

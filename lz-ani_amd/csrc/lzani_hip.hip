@@ -95,6 +95,7 @@ struct lzani_ctx {
     u64 dir_stride = 0, ent_stride = 0;
     unsigned long long* d_cursor = nullptr;
     u32* d_blkctr = nullptr;      // k_pairs_blk: one pair counter per block
+    int blk_launches = 0;         // launches of k_pairs_blk in the last run
     int blk_fold = -1;            // k_pairs_blk: LDS filter = global filter folded 2^blk_fold times (-1: not decided yet)
 
     lzani_timing tm{};
@@ -420,6 +421,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     c->tm = lzani_timing{};
     c->kmers_ready = false;                       // recomputed inside every run: it is part of the path's work
     c->batches_last_run = 0;
+    c->blk_launches = 0;
     if (n_rows == 0) return LZANI_OK;
     const u64 n_pairs = row_off[n_rows];
     for (u32 k = 0; k < n_rows; ++k) {
@@ -574,6 +576,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 const size_t lds = (size_t)(BLK_WAVES * SEED_LDS_WORDS + fw) * 4;
                 HIPCHK(c, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 pa.fmask = c->fmask >> c->blk_fold;
+                c->blk_launches += 1;
                 const dim3 gb((u32)std::min<u64>((waves + BLK_CHUNK - 1) / BLK_CHUNK, (u64)c->n_cus * 2)), bb(64 * BLK_WAVES);
                 if (nf && defp) hipLaunchKernelGGL((k_pairs_blk<true, true>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
                 else if (nf) hipLaunchKernelGGL((k_pairs_blk<true, false>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
@@ -870,7 +873,7 @@ int lzani_get_layout(const lzani_ctx* c, lzani_layout_info* o)
     o->slots = c->slots; o->batches_last_run = c->batches_last_run;
     o->bytes_per_slot = 4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride);
     o->bytes_genomes = c->total_nm * (16 + 8) + (c->d_kmL ? c->total_nm * 64 * 8 : 0);
-    o->join_lists = c->join_mode; o->reserved = 0;
+    o->join_lists = c->join_mode; o->block_launches = c->blk_launches;
     return LZANI_OK;
 }
 

@@ -1168,7 +1168,10 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 // query positions out of four without leaving the CU: the tag-word probes -- random 4-byte reads that cost a
 // 128-byte L2 line each, the traffic that bounds the viral pair kernel at the L2 -- are made for the rest only.
 // Every barrier is reached by all 16 waves the same number of times: chunk and segment bounds are block-uniform.
-enum { BLK_WAVES = 16, BLK_CHUNK = 256 };
+#ifndef LZANI_BLK_CHUNK
+#define LZANI_BLK_CHUNK 128
+#endif
+enum { BLK_WAVES = 16, BLK_CHUNK = LZANI_BLK_CHUNK };
 template <bool NFREE, bool DEFP>
 __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32 fwords, u32 fold, u32* __restrict__ blkctr)
 {

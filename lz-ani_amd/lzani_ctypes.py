@@ -46,7 +46,7 @@ class LayoutInfo(C.Structure):
     _fields_ = [("key_bits", C.c_int32), ("dir_bits", C.c_int32), ("pos_bits", C.c_int32), ("tag_mask", C.c_uint32),
                 ("kmer_words", C.c_int32), ("bucket_table", C.c_int32), ("tag_words", C.c_int32), ("n_free", C.c_int32),
                 ("slots", C.c_uint32), ("batches_last_run", C.c_uint32), ("bytes_per_slot", C.c_uint64),
-                ("bytes_genomes", C.c_uint64), ("join_lists", C.c_int32), ("reserved", C.c_int32)]
+                ("bytes_genomes", C.c_uint64), ("join_lists", C.c_int32), ("block_launches", C.c_int32)]
 
 
 def build_library(force=False):

@@ -569,6 +569,71 @@ def test_join_form_of_candidate_detection(monkeypatch):
             e += 1
 
 
+def test_block_kernel_with_lds_filter(monkeypatch):
+    """Rows of >= 128 pairs run by blocks of 16 waves that keep the reference's presence filter in LDS (k_pairs_blk,
+    with the null chain where the parameters are the defaults): whole matrices against the oracle -- N-free and with N,
+    default and other parameters, 149-pair rows cut across chunks of 128, a filtered CSR with long and short rows --
+    and equal to the wave kernel's results; the layout info says which kernel ran."""
+    _, seqs = SG.make_set(150, 31, lmin=17000, lmax=20000, fam=10)      # (tag words need >= 2^15 buckets)
+    withn = [s.copy() for s in seqs]
+    for k in range(0, 150, 7):
+        withn[k][300:300 + 5 + k % 40] = 5
+    want = {}
+    for name, data, prms in (("N-free", seqs, (None, dict(reg=30, aw=20))), ("with N", withn, (None,))):
+        for prm in prms:
+            eng = L.Engine(prm)
+            eng.set_genomes(data)
+            got = eng.all2all()
+            lay = eng.layout()
+            eng.close()
+            assert lay["block_launches"] == 1 and lay["tag_words"] == 1, (name, prm)
+            want[(name, str(prm))] = O.oracle_all2all(data, prm, threads=16)
+            bad = np.argwhere((got != want[(name, str(prm))]).any(axis=2))
+            assert len(bad) == 0, (name, prm, bad[:3].tolist())
+    # the wave kernel on the same set
+    monkeypatch.setenv("LZANI_NO_BLOCK_KERNEL", "1")
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    got = eng.all2all()
+    assert eng.layout()["block_launches"] == 0
+    monkeypatch.delenv("LZANI_NO_BLOCK_KERNEL")
+    assert np.array_equal(got, want[("N-free", "None")])
+    # filtered rows: 35 rows of 140 queries, 34 rows of 1-3 queries in between, an empty row
+    st = SG.Stream(5)
+    ref_ids, row_off, q = [], [0], []
+    for r in range(0, 140, 2):
+        if r % 4 == 0:
+            qs = [x for x in range(150) if x != r][:140]
+        elif r == 70:
+            qs = []
+        else:
+            qs = [x for x in ((r + 1 + st.randint(0, 100)) % 150 for _ in range(st.randint(1, 3))) if x != r]
+        ref_ids.append(r); q += qs; row_off.append(len(q))
+    ref_ids = np.array(ref_ids, np.uint32); row_off = np.array(row_off, np.uint64); q = np.array(q, np.uint32)
+    out = eng.run_rows(ref_ids, row_off, q).reshape(-1, 3)
+    full = want[("N-free", "None")]
+    e = 0
+    for k, r in enumerate(ref_ids):
+        for x in q[int(row_off[k]):int(row_off[k + 1])]:
+            assert tuple(out[e]) == tuple(full[r, x]), (k, r, x)
+            e += 1
+    # the same rows, the long ones only: the block kernel on a CSR
+    keep = [k for k in range(len(ref_ids)) if row_off[k + 1] - row_off[k] >= 128]
+    r2 = ref_ids[keep]
+    q2 = np.concatenate([q[int(row_off[k]):int(row_off[k + 1])] for k in keep])
+    off2 = np.zeros(len(keep) + 1, np.uint64)
+    off2[1:] = np.cumsum([int(row_off[k + 1] - row_off[k]) for k in keep])
+    out2 = eng.run_rows(r2, off2, q2).reshape(-1, 3)
+    assert eng.layout()["block_launches"] == 1
+    eng.close()
+    e = 0
+    for k, r in enumerate(r2):
+        for x in q2[int(off2[k]):int(off2[k + 1])]:
+            assert tuple(out2[e]) == tuple(full[r, x]), (k, r, x)
+            e += 1
+    assert e == len(q2) and len(keep) >= 30
+
+
 def test_last_slot_number_is_not_the_invalid_key(monkeypatch):
     """Found by the differential fuzz (tools/fuzz_gpu.py, seed 1202 case 1361) with the join and the sort-based index
     build forced on: both sort 64-bit keys `number || hash || position` whose invalid form is all ones, looking only at
