@@ -16,7 +16,7 @@ st = SG.Stream(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
 medium = len(sys.argv) > 3 and sys.argv[3] == "medium"
 large = len(sys.argv) > 3 and sys.argv[3] == "large"
-t0, it, bad = time.time(), 0, 0
+t0, it, bad, blk = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     it += 1
     prm, seqs = U.fuzz_case_large(st) if large else U.fuzz_case_medium(st) if medium else U.fuzz_case(st)
@@ -27,6 +27,19 @@ while time.time() - t0 < budget:
     if not np.array_equal(got, want):
         bad += 1
         print("MISMATCH", prm, [len(s) for s in seqs], np.argwhere((got != want).any(axis=2))[:3].tolist(), flush=True)
+    if medium:                                        # rows of >= 128 pairs (every query 45 times): the block kernel with the LDS filter
+        n = len(seqs)
+        ref_ids = np.arange(n, dtype=np.uint32)
+        qs = [[x for x in range(n) if x != r] * 45 for r in range(n)]
+        row_off = np.zeros(n + 1, np.uint64)
+        row_off[1:] = np.cumsum([len(x) for x in qs])
+        qq = np.array([x for row in qs for x in row], np.uint32)
+        out = eng.run_rows(ref_ids, row_off, qq).reshape(-1, 3)
+        blk += eng.layout()["block_launches"]
+        wantr = np.concatenate([want[r, qs[r]] for r in range(n)])
+        if not np.array_equal(out, wantr):
+            bad += 1
+            print("ROWS MISMATCH", prm, [len(s) for s in seqs], np.argwhere((out != wantr).any(axis=1))[:3].tolist(), flush=True)
     if it % 4 == 0 and not large:                     # the alignment instantiation: regions of one row (the oracle wrapper holds 4,096 regions per pair: not at Mbp sizes)
         n = len(seqs)
         r = it % n
@@ -47,5 +60,5 @@ while time.time() - t0 < budget:
     eng.close()
     if it % 500 == 0:
         print("...", it, "cases", flush=True)
-print("cases", it, "mismatches", bad)
+print("cases", it, "mismatches", bad, "block-kernel launches", blk)
 sys.exit(1 if bad else 0)
