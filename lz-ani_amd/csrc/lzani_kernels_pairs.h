@@ -23,6 +23,8 @@ enum { AQ_NONE = 0x7FFFFFFF };
 // come from a join with the query's sorted k-mer list (long genomes) instead of a probe per query position
 // the wave's vote as the compare result itself (HIP's __ballot goes through an int: v_cndmask 0/1 + v_cmp_ne per vote)
 __device__ __forceinline__ u64 wballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+// a byte in all four bytes of a word: one byte permute (a 32-bit multiply by 0x01010101 runs at quarter rate)
+__device__ __forceinline__ u32 rep4(u32 b) { return __builtin_amdgcn_perm(b, b, 0u); }
 
 template <bool FAST, bool BK = false, bool JOIN = false, bool CHAIN = false, bool LFLT = false>
 struct DevWave {
@@ -312,7 +314,7 @@ struct DevWave {
         if constexpr (BK) {
             const bool valid = hq != KM_INVALID;
             const u32 w = I.tw[valid ? hq >> tb : 0u];
-            const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);       // a zero byte = a slot with this tag
+            const u32 x = w ^ rep4(0x80u | (hq & I.tagmask));       // a zero byte = a slot with this tag
             ac = (u32)(valid & ((((x - 0x01010101u) & ~x & 0x80808080u) != 0) | (w == TW_OVERFLOW)));
         } else if (hq != KM_INVALID) {
             const u32 b = hq >> tb, tag = hq & I.tagmask;
@@ -448,18 +450,18 @@ struct DevWave {
             for (int c = 0; c < 4; ++c) {
                 if (scan_pos >= iend || ncand >= AQ_CAP) break;               // wave-uniform
                 const int p = scan_pos + lane;
-                const u32 x = w[c] ^ ((0x80u | (hq[c] & I.tagmask)) * 0x01010101u);   // a zero byte = a slot with this tag
+                const u32 x = w[c] ^ rep4(0x80u | (hq[c] & I.tagmask));   // a zero byte = a slot with this tag
                 const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;                     // its lowest flag is exact
                 const bool ovf = w[c] == TW_OVERFLOW;
                 const bool cnd = valid[c] & ((z != 0) | ovf);
                 const u64 bal = wballot(cnd);
-                if (bal) {
-                    const int at = ncand + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                {
+                    // no lane-dependent branch (exec-mask bookkeeping is scalar work): a lane without a candidate writes
+                    // the spare last entry (ncand < AQ_CAP at this point, so at <= AQ_CAP - 1 + 63 < AQ_LDS_CAND - 1)
+                    const int at = cnd ? ncand + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u)) : AQ_LDS_CAND - 1;
                     const bool cplx = ovf | ((z & (z - 1)) != 0);                       // bucket overflow, or the tag in two slots
-                    if (cnd) {
-                        cq[at] = (u32)p;
-                        cq[AQ_LDS_CAND + at] = cplx ? (u32)AQ_COMPLEX : 4u * (hq[c] >> tb) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
-                    }
+                    cq[at] = (u32)p;
+                    cq[AQ_LDS_CAND + at] = cplx ? (u32)AQ_COMPLEX : 4u * (hq[c] >> tb) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
                     ncand += popc64(bal);
                 }
                 scan_pos = imin(scan_pos + 64, iend);
@@ -479,7 +481,7 @@ struct DevWave {
             const u32 hq = qkL[(u32)qp];
             const bool ok = live & (hq != KM_INVALID);
             const u32 w = I.tw[ok ? hq >> tb : 0u];
-            const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);
+            const u32 x = w ^ rep4(0x80u | (hq & I.tagmask));
             const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
             const bool cplx = (w == TW_OVERFLOW) | ((z & (z - 1)) != 0) | (z == 0);
             slot = (!ok | cplx) ? (u32)AQ_COMPLEX : 4u * (hq >> tb) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
@@ -581,7 +583,7 @@ struct DevWave {
         const u32 hq = qkL[(u32)(i + lane)];
         const bool valid = (lane < nt) & (hq != KM_INVALID);
         const u32 w = I.tw[valid ? hq >> tb : 0u];
-        const u32 x = w ^ ((0x80u | (hq & I.tagmask)) * 0x01010101u);
+        const u32 x = w ^ rep4(0x80u | (hq & I.tagmask));
         const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
         return wballot(valid & ((z != 0) | (w == TW_OVERFLOW)));
     }
@@ -999,7 +1001,7 @@ __device__ __forceinline__ void join_candidates(const u32* __restrict__ tw, int 
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const u32 hq = ((u32)(e[c] >> posbits)) & hmask, pos = (u32)e[c] & pmask;
-            const u32 x = w[c] ^ ((0x80u | (hq & tagmask)) * 0x01010101u);
+            const u32 x = w[c] ^ rep4(0x80u | (hq & tagmask));
             const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
             if ((k0 + 64 * c + lane < n_keys) & ((z != 0) | (w[c] == TW_OVERFLOW))) atomicOr(&bits32[pos >> 5], 1u << (pos & 31));
         }

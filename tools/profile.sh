@@ -12,7 +12,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
 timeout -k 10 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$B" --steps 4 --warmup 1 --cpu-sample 0 > "$OUT/stats.log" 2>&1 || { tail -5 "$OUT/stats.log"; exit 1; }
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES"; do
     name=$(echo "$set" | tr ' ' '_' | cut -c1-40)
     timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc_$name" -- python3 "$B" --steps 1 --warmup 0 --cpu-sample 0 > "$OUT/pmc_$name.log" 2>&1 || { echo "pmc pass '$set' failed"; tail -3 "$OUT/pmc_$name.log"; }
 done
