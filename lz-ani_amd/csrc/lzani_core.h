@@ -500,10 +500,16 @@ LZ_HD int popc32(u32 x) { return popc64((u64)x); }
 // candidate, for a whole batch of the anchor queue (lzani_kernels_pairs.h: refill).
 //   bits 0..aw-1  backward qual bits (ext_lane: symbol j back and the ar-1 before it all match), j < aw
 //   bit 30        the first aw backward symbols hold more than am mismatches (the scan breaks inside them)
-//   bit 31        the forward extension is provably empty: its first aw symbols break the scan and none qualifies
+//   bit 31        the forward extension is provably empty: its first aw symbols break the scan and none qualifies up to
+//                 the break
+//   aw <= 15 only (the bits above the qual bits are free):
+//   bit 29        the forward extension is KNOWN: its first aw symbols break the scan (at the (am+1)-th mismatch, since
+//                 every window up to there starts at the match), so it ends at the last qualifying symbol before the break:
+//   bits 24..28   its length e (0 = empty; then bit 31 is set too), bits 20..23 the mismatches among its e symbols
 // An extension is empty iff no symbol qualifies up to the break; if the first aw symbols already break the scan
 // the later ones do not matter.  A record that proves nothing (aw > 30, a text end nearby) has every qual bit set.
-enum : u32 { EXT_REC_NONE = 0x3FFFFFFFu, EXT_REC_BRKB = 0x40000000u, EXT_REC_NULLF = 0x80000000u };
+enum : u32 { EXT_REC_NONE = 0x3FFFFFFFu, EXT_REC_FWDK = 0x20000000u, EXT_REC_BRKB = 0x40000000u, EXT_REC_NULLF = 0x80000000u };
+LZ_HD u32 ext_rec_none(int aw) { return aw <= 15 ? 0x00007FFFu : (u32)EXT_REC_NONE; }
 LZ_HD u32 ext_qual32(u32 B, int ar)            // qual bits of a chunk's first 32 symbols (no earlier chunk)
 {
     const int a = ar < 1 ? 1 : ar;
@@ -516,7 +522,7 @@ LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q,
 {
     if (P.aw > 30) return EXT_REC_NONE;
     const u32 wm = (u32)lowmask(P.aw);
-    u32 rec = EXT_REC_NONE;
+    u32 rec = ext_rec_none(P.aw);
     if (qp >= 32 && pos >= 32) {                                       // all 32 symbols before the match exist
         const u32 Bb = brev32(lane_mism32(R, Q, qp - 32, pos - 32));   // bit j = symbol qp-1-j / pos-1-j
         rec = (ext_qual32(Bb, P.ar) & wm) | (popc32(Bb & wm) > P.am ? (u32)EXT_REC_BRKB : 0u);
@@ -524,7 +530,16 @@ LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q,
     const int fq = qp + al, fr = pos + al;
     if (imin(Q.len - fq, R.len - fr) >= P.aw) {
         const u32 Bf = lane_mism32(R, Q, fq, fr);
-        if (popc32(Bf & wm) > P.am && (ext_qual32(Bf, P.ar) & wm) == 0) rec |= EXT_REC_NULLF;
+        if (popc32(Bf & wm) > P.am) {                                   // the scan breaks at the (am+1)-th mismatch
+            u32 x = Bf & wm;
+            for (int k = 0; k < P.am; ++k) x &= x - 1u;
+            const u32 qf = ext_qual32(Bf, P.ar) & (u32)lowmask((int)__builtin_ctz(x) + 1);
+            if (qf == 0) rec |= EXT_REC_NULLF | (P.aw <= 15 ? (u32)EXT_REC_FWDK : 0u);
+            else if (P.aw <= 15) {
+                const int e = 32 - (int)__builtin_clz(qf);               // ends at the last qualifying symbol
+                rec |= EXT_REC_FWDK | ((u32)e << 24) | ((u32)popc32(Bf & (u32)lowmask(e)) << 20);
+            }
+        }
     }
     return rec;
 }
@@ -711,9 +726,9 @@ struct PairMachine {
                 // short region" for as many events as it lasts: exactly the updates of the null event below, nothing
                 // else touched; what it leaves unfinished it hands back (the round done, or the event found).
                 if (trk & (lit == 0)) {
-                    int last_blen = 0;
-                    in_hand = w.null_chain(i, r_end, prev_rs, prev_re, pre_lit, last_blen, adv, bpos, blen);
-                    if (last_blen) { g.cl = last_blen; g.clit = 0; g.nl = 0; }     // discard + the match of the last null event
+                    int last_cl = 0, last_clit = 0;
+                    in_hand = w.null_chain(i, r_end, prev_rs, prev_re, pre_lit, last_cl, last_clit, adv, bpos, blen);
+                    if (last_cl) { g.cl = last_cl; g.clit = last_clit; g.nl = 0; }  // discard + the match (+ forward extension) of the last event
                 }
             }
             const bool hit = in_hand == 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);
@@ -755,6 +770,10 @@ struct PairMachine {
                 u32 rec = EXT_REC_NONE;
                 const bool have_rec = !ALN && w.ext_record(rec);
                 const bool null_f = have_rec && (rec & EXT_REC_NULLF);
+                // (aw <= 15) the forward extension itself may be in the record: then neither side of it needs the texts
+                const bool fwd_k = have_rec && P.aw <= 15 && (rec & EXT_REC_FWDK);
+                const int fe = fwd_k ? (int)((rec >> 24) & 31u) : 0, fmm = fwd_k ? (int)((rec >> 20) & 15u) : 0;
+                const bool fwd_free = null_f | fwd_k;
                 const bool null_b = nb == 0 || (have_rec && ext_rec_null_bwd(rec, imin(avail, imin(i, bpos)), P.aw));
                 if (null_f & null_b) {
                     // the null event: no text access, no lane work; the match opens a region on its own
@@ -766,8 +785,8 @@ struct PairMachine {
                     continue;
                 }
                 int b = 0;
-                if (null_b | null_f) {
-                    // one side is known to be empty: fetch and scan the other one only
+                if (null_b | fwd_free) {
+                    // one side is known (empty, or the forward extension from the record): fetch and scan the other one only
                     if (!null_b) { Bb = w.mism_bwd(i, bpos, nb); b = extend_backward(i, bpos, avail, true, Bb); }
                 } else {
                     // the first chunks of the backward and of the forward extension are fetched together (one
@@ -789,8 +808,12 @@ struct PairMachine {
                     prev_rs = i - b;
                 } else { pre_lit = avail; prev_rs = i; }
                 match_run(i, bpos, blen);
-                if (null_f) {                                           // (then !ALN) the forward extension is empty
+                if (fwd_free) {                                         // (then !ALN) the forward extension is empty or known
                     i += blen; r_end = bpos + blen; lit = 0; trk = true;
+                    if (fe > 0) {                                       // = extend_forward: fe symbols, the last one a match
+                        g.cl += fe - fmm; g.clit += g.nl + fmm; g.nl = 0;
+                        i += fe; r_end += fe;
+                    }
                     prev_re = i;
                     continue;
                 }

@@ -577,7 +577,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 HIPCHK(c, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 pa.fmask = c->fmask >> c->blk_fold;
                 c->blk_launches += 1;
-                const dim3 gb((u32)std::min<u64>((waves + BLK_CHUNK - 1) / BLK_CHUNK, (u64)c->n_cus * 2)), bb(64 * BLK_WAVES);
+                const dim3 gb((u32)std::min<u64>((waves + BLK_CHUNK_MIN - 1) / BLK_CHUNK_MIN, (u64)c->n_cus * 2)), bb(64 * BLK_WAVES);
                 if (nf && defp) hipLaunchKernelGGL((k_pairs_blk<true, true>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
                 else if (nf) hipLaunchKernelGGL((k_pairs_blk<true, false>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
                 else if (defp) hipLaunchKernelGGL((k_pairs_blk<false, true>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);

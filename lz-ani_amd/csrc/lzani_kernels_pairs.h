@@ -516,7 +516,7 @@ struct DevWave {
         a_len = plain ? al0 : -1 - al0;
         // what a distant event at this candidate needs to see that neither extension moves, worked out now, by the
         // lane, for the whole batch at once
-        a_ext = (simple & !lng) ? null_ext_record(P, R, Q, qp, pos, al0) : (u32)EXT_REC_NONE;
+        a_ext = (simple & !lng) ? null_ext_record(P, R, Q, qp, pos, al0) : ext_rec_none(P.aw);
         // A candidate the lane has resolved to a match shorter than mal is no anchor and never an event -- the tag of
         // another k-mer in the bucket, about as many per pair as there are true anchors: it leaves the queue here, all
         // of a batch in one stable compaction (lane permute, no LDS memory), instead of costing the sequential scan a
@@ -630,11 +630,11 @@ struct DevWave {
     //   returns 0   nothing in hand (queue empty or not covering the tracking steps, query or reference end near)
     //   returns 1   the tracking round of step i is done: pre_seed / pre_rk0 / pre_rk1 / pre_qk, for find_event
     //   returns 2   the next event is found but is not a null event: adv, bpos, blen (consumed from the queue)
-    // i, r_end, prev_rs, prev_re, pre_lit are the machine's; last_blen != 0 = null events were committed, the open
-    // region is the last one's match (cl = last_blen, clit = nl = 0).  Wait states of gfx950 are placed by hand
+    // i, r_end, prev_rs, prev_re, pre_lit are the machine's; last_cl != 0 = events were committed, the open region is the
+    // last one's match and forward extension (cl = last_cl, clit = last_clit, nl = 0).  Wait states of gfx950 are placed by hand
     // (VALU-written mask -> VALU use: 2; lane select / VMEM base written by a VALU: the prologue is long enough).
-    __device__ __forceinline__ int null_chain(int& i, int& r_end, int& prev_rs, int& prev_re, int& pre_lit, int& last_blen,
-                                              int& adv, int& bpos, int& blen)
+    __device__ __forceinline__ int null_chain(int& i, int& r_end, int& prev_rs, int& prev_re, int& pre_lit, int& last_cl,
+                                              int& last_clit, int& adv, int& bpos, int& blen)
     {
         static_assert(!CHAIN || (FAST && BK), "the null chain reads the anchor queue");
         enum { MQD = 40, MRD = 40, MSL = 7, REG = 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };    // params.h:34-48
@@ -659,6 +659,7 @@ struct DevWave {
         asm volatile(
             "s_mov_b32 %[code], 0\n\t"
             "s_mov_b32 %[lastb], 0\n\t"
+            "s_mov_b32 %[lastlit], 0\n\t"
             "s_nop 3\n"
             "Lnc_top_%=:\n\t"
             // the queue head: candidates the last match has passed go
@@ -708,7 +709,7 @@ struct DevWave {
             "s_sub_i32 %[t1], %[pre], %[prs]\n\t"
             "s_cmp_ge_i32 %[t1], %[REG]\n\t"
             "s_cbranch_scc1 Lnc_chk_%=\n\t"
-            "s_bitcmp0_b32 %[rec], 31\n\t"
+            "s_bitcmp0_b32 %[rec], 29\n\t"                  // the forward extension must be in the record (empty or not)
             "s_cbranch_scc1 Lnc_chk_%=\n\t"
             "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
             "s_add_i32 %[t1], %[t1], %[plit]\n\t"           // avail
@@ -766,9 +767,12 @@ struct DevWave {
             // the null event
             "s_mov_b32 %[plit], %[t1]\n\t"
             "s_mov_b32 %[prs], %[ap]\n\t"
-            "s_mov_b32 %[lastb], %[blen]\n\t"
-            "s_add_i32 %[i], %[ap], %[blen]\n\t"
-            "s_add_i32 %[rend], %[bpos], %[blen]\n\t"
+            "s_bfe_u32 %[t0], %[rec], 0x50018\n\t"          // e: the forward extension's length (bits 24..28)
+            "s_bfe_u32 %[lastlit], %[rec], 0x40014\n\t"     // its mismatches (bits 20..23) = the literals of the open region
+            "s_add_i32 %[t2], %[blen], %[t0]\n\t"
+            "s_sub_i32 %[lastb], %[t2], %[lastlit]\n\t"     // its matches: the anchor + the extension's
+            "s_add_i32 %[i], %[ap], %[t2]\n\t"
+            "s_add_i32 %[rend], %[bpos], %[t2]\n\t"
             "s_mov_b32 %[pre], %[i]\n\t"
             "s_add_i32 %[qh], %[qh], 1\n\t"
             "s_mov_b32 %[code], 0\n\t"
@@ -785,7 +789,7 @@ struct DevWave {
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_nop 4"
             : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit),
-              [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_blen), [rec] "=&s"(rec),
+              [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec),
               [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [m] "=&s"(m), [seed] "=&s"(seed),
               [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq)
             : [qc] "s"(q_cnt), [ilim] "s"(ilim), [rlim] "s"(rlim), [qks] "s"(qks), [rks] "s"(rks),
@@ -1171,9 +1175,9 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 // 128-byte L2 line each, the traffic that bounds the viral pair kernel at the L2 -- are made for the rest only.
 // Every barrier is reached by all 16 waves the same number of times: chunk and segment bounds are block-uniform.
 #ifndef LZANI_BLK_CHUNK
-#define LZANI_BLK_CHUNK 128
+#define LZANI_BLK_CHUNK 256
 #endif
-enum { BLK_WAVES = 16, BLK_CHUNK = LZANI_BLK_CHUNK };
+enum { BLK_WAVES = 16, BLK_CHUNK = LZANI_BLK_CHUNK, BLK_CHUNK_MIN = 32 };   // chunk of pair tickets: at most / at least
 template <bool NFREE, bool DEFP>
 __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32 fwords, u32 fold, u32* __restrict__ blkctr)
 {
@@ -1181,25 +1185,32 @@ __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32
     const int lane = threadIdx.x & 63;
     u32* const lds = s_dyn + (threadIdx.x >> 6) * SEED_LDS_WORDS;
     u32* const flt = s_dyn + BLK_WAVES * SEED_LDS_WORDS;
-    u32* const ctl = s_dyn + SEED_BM_WORDS;        // two words in wave 0's candidate buffer: dead while the block is between segments
+    u32* const ctl = s_dyn + SEED_BM_WORDS;        // three words in wave 0's candidate buffer: dead while the block is between segments
     for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[k] = 0;
     u32 qx = xcc_id() % NQUEUES, dry = 0;
     for (;;) {
         __syncthreads();                           // (ctl is free: nobody is inside a pair)
+        const u32 rb = a.qb[qx], re = a.qb[qx + 1];
+        const u64 base = a.qcum[rb], total = a.qcum[re] - base;
         if (threadIdx.x == 0) {
-            const unsigned long long t = atomicAdd(&a.cursor[qx], (unsigned long long)BLK_CHUNK);
-            ctl[0] = (u32)t; ctl[1] = (u32)(t >> 32);
+            // guided chunks: a share of what the queue has left (read without a lock: any size is a valid chunk), so that
+            // the barriers are few while the queue is long and the blocks finish together when it ends
+            const unsigned long long seen = __hip_atomic_load(&a.cursor[qx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 left = total > seen ? total - seen : 0;
+            u64 ch = left / (2 * (gridDim.x / NQUEUES + 1));
+            ch = ch < BLK_CHUNK_MIN ? BLK_CHUNK_MIN : ch > BLK_CHUNK ? BLK_CHUNK : ch;
+            const unsigned long long t = atomicAdd(&a.cursor[qx], (unsigned long long)ch);
+            ctl[0] = (u32)t; ctl[1] = (u32)(t >> 32); ctl[2] = (u32)ch;
         }
         __syncthreads();
         const u64 t0 = ((u64)ctl[1] << 32) | ctl[0];
-        const u32 rb = a.qb[qx], re = a.qb[qx + 1];
-        const u64 base = a.qcum[rb], total = a.qcum[re] - base;
+        const u64 chunk = ctl[2];
         if (t0 >= total) {                         // this queue is dry (block-uniform): move on, leave after NQUEUES dry queues
             if (++dry >= NQUEUES) break;
             qx = (qx + 1) % NQUEUES;
             continue;
         }
-        const u64 t1 = t0 + BLK_CHUNK < total ? t0 + BLK_CHUNK : total;
+        const u64 t1 = t0 + chunk < total ? t0 + chunk : total;
         u32 lo = row_of_ticket(a.qcum, rb, re, base + t0);
         for (u64 cur = t0; cur < t1; ++lo) {       // the rows of the chunk (rows without pairs fall through)
             const u64 row_end = a.qcum[lo + 1] - base;

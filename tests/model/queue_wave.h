@@ -69,7 +69,7 @@ struct QueueWave : Base {
         const bool lng = n == AQ_LANE_CAP && bound > AQ_LANE_CAP;
         a_ref[k] = (u32)pos | (lng ? (u32)AQ_LONG : 0u);
         a_len[k] = n;
-        a_ext[k] = lng ? (u32)EXT_REC_NONE : null_ext_record(this->P, R, Q, qp, pos, n);
+        a_ext[k] = lng ? ext_rec_none(this->P.aw) : null_ext_record(this->P, R, Q, qp, pos, n);
     }
     bool ext_record(u32& x) const
     {
