@@ -507,6 +507,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     const Params& q = c->P;
     const bool defp = q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3;
     std::vector<char> launched(n_batches, 0);
+    const char* const bkenv = getenv("LZANI_BLOCK_KERNEL");
     DevBuf<unsigned long long> d_cbits;                      // join form: one candidate bitmap per resident wave
     u64 cbits_stride = 0;
     if (c->join_mode && !rs) {
@@ -558,8 +559,10 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (nf) LZ_PAIRS_JOIN(true, false);
                 else if (defp) LZ_PAIRS_JOIN(false, true);
                 else LZ_PAIRS_JOIN(false, false);
-            } else if (tw && c->fl_stride && (e1 - e0) / rows >= 128 && !getenv("LZANI_NO_BLOCK_KERNEL")) {
-                // probe form, rows of hundreds of pairs: blocks of 16 waves with the reference's presence filter in LDS
+            } else if (tw && c->fl_stride && (e1 - e0) / rows >= 128 && (bkenv ? *bkenv == '1' : query_ids == nullptr)) {
+                // probe form, dense rows of hundreds of pairs: blocks of 16 waves with the reference's presence filter in LDS.
+                // (The rows a kmer-db filter leaves hold related pairs, where most positions pass the filter: BASELINE
+                // configs[4] at full size is 6 % slower this way; LZANI_BLOCK_KERNEL=1/0 overrides.)
                 if (!c->d_blkctr) HIPCHK(c, hipMalloc(&c->d_blkctr, (size_t)c->n_cus * 2 * 4));
                 const void* kf = nf ? (defp ? (const void*)k_pairs_blk<true, true> : (const void*)k_pairs_blk<true, false>)
                                     : (defp ? (const void*)k_pairs_blk<false, true> : (const void*)k_pairs_blk<false, false>);

@@ -591,12 +591,12 @@ def test_block_kernel_with_lds_filter(monkeypatch):
             bad = np.argwhere((got != want[(name, str(prm))]).any(axis=2))
             assert len(bad) == 0, (name, prm, bad[:3].tolist())
     # the wave kernel on the same set
-    monkeypatch.setenv("LZANI_NO_BLOCK_KERNEL", "1")
+    monkeypatch.setenv("LZANI_BLOCK_KERNEL", "0")
     eng = L.Engine()
     eng.set_genomes(seqs)
     got = eng.all2all()
     assert eng.layout()["block_launches"] == 0
-    monkeypatch.delenv("LZANI_NO_BLOCK_KERNEL")
+    monkeypatch.delenv("LZANI_BLOCK_KERNEL")
     assert np.array_equal(got, want[("N-free", "None")])
     # filtered rows: 35 rows of 140 queries, 34 rows of 1-3 queries in between, an empty row
     st = SG.Stream(5)
@@ -611,6 +611,8 @@ def test_block_kernel_with_lds_filter(monkeypatch):
         ref_ids.append(r); q += qs; row_off.append(len(q))
     ref_ids = np.array(ref_ids, np.uint32); row_off = np.array(row_off, np.uint64); q = np.array(q, np.uint32)
     out = eng.run_rows(ref_ids, row_off, q).reshape(-1, 3)
+    assert eng.layout()["block_launches"] == 0                 # filtered rows go to the wave kernel unless told otherwise
+    monkeypatch.setenv("LZANI_BLOCK_KERNEL", "1")
     full = want[("N-free", "None")]
     e = 0
     for k, r in enumerate(ref_ids):

@@ -34,7 +34,9 @@ while time.time() - t0 < budget:
         row_off = np.zeros(n + 1, np.uint64)
         row_off[1:] = np.cumsum([len(x) for x in qs])
         qq = np.array([x for row in qs for x in row], np.uint32)
+        os.environ["LZANI_BLOCK_KERNEL"] = "1"           # (filtered rows take the wave kernel by default)
         out = eng.run_rows(ref_ids, row_off, qq).reshape(-1, 3)
+        del os.environ["LZANI_BLOCK_KERNEL"]
         blk += eng.layout()["block_launches"]
         wantr = np.concatenate([want[r, qs[r]] for r in range(n)])
         if not np.array_equal(out, wantr):
