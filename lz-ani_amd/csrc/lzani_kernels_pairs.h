@@ -14,8 +14,10 @@ namespace lzani {
 enum { SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5), NQUEUES = 8 };
 // anchor queue of a wave (tag-word instantiation): up to AQ_CAP resolved candidates, one per lane; candidates are
 // detected ahead of the scan in chunks of 64 query positions, at most AQ_MAXCHUNKS per refill, and compacted
-// through 2 x AQ_LDS_CAND words of LDS (positions, bucket slots)
-enum { AQ_CAP = 64, AQ_MAXCHUNKS = 32, AQ_LANE_CAP = 32, AQ_LDS_CAND = 128, SEED_LDS_WORDS = SEED_BM_WORDS + 2 * AQ_LDS_CAND };
+// through 2 x AQ_LDS_CAND words of LDS (positions, bucket slots) -- the first words of the wave's seed bitmap, which no
+// round is using while a refill runs and which the refill leaves all zero again (2 KB of LDS per wave in all)
+enum { AQ_CAP = 64, AQ_MAXCHUNKS = 32, AQ_LANE_CAP = 32, AQ_LDS_CAND = 128, SEED_LDS_WORDS = SEED_BM_WORDS };
+static_assert(2 * AQ_LDS_CAND <= SEED_BM_WORDS, "the candidate buffers of refill live in the seed bitmap");
 enum : u32 { AQ_COMPLEX = 0x80000000u, AQ_LONG = 0x40000000u, AQ_POS = 0x3FFFFFFFu };
 enum { AQ_NONE = 0x7FFFFFFF };
 
@@ -169,9 +171,10 @@ struct DevWave {
     __device__ __forceinline__ bool seed_prefilter(u32 rk0, u32 rk1, u32 qk) const
     {
         // no lane-dependent branch (each costs two to three scalar instructions of exec-mask bookkeeping and the
-        // kernel is bound by the scalar pipe): a lane without a k-mer ORs nothing into / clears / reads its own
-        // scratch word behind the bitmap (the candidate buffer of refill, dead between refills)
-        const u32 scratch = SEED_BM_WORDS + (u32)lane;
+        // kernel is bound by the scalar pipe): a lane without a k-mer ORs nothing into / reads (masked) / clears word
+        // `lane` of the bitmap itself -- the clear comes after every lane's read, and every word a round sets is
+        // cleared by the round anyway
+        const u32 scratch = (u32)lane;
         const u32 b0 = bm_hash(rk0), b1 = bm_hash(rk1), bq = bm_hash(qk);
         const bool v0 = rk0 != KM_INVALID, v1 = rk1 != KM_INVALID, vq = qk != KM_INVALID;
         const u32 w0 = v0 ? b0 >> 5 : scratch, w1 = v1 ? b1 >> 5 : scratch, wq = vq ? bq >> 5 : scratch;
@@ -400,7 +403,7 @@ struct DevWave {
 #ifdef LZANI_CHAIN_STATS
         st[7] += 1;
 #endif
-        u32* const cq = bitmap + SEED_BM_WORDS;
+        u32* const cq = bitmap;                                 // (all zero again when refill returns)
         const int tb = I.kb - I.dirbits;
         scan_pos = imax(scan_pos, from);
         int ncand = 0;
@@ -476,6 +479,9 @@ struct DevWave {
         const bool live = lane < q_cnt;
         const int qp = live ? (int)cq[lane] : 0;
         u32 slot = live ? cq[AQ_LDS_CAND + lane] : (u32)AQ_COMPLEX;
+        lds_order();
+#pragma unroll
+        for (int k = 0; k < 2 * AQ_LDS_CAND; k += 64) cq[k + lane] = 0;     // the seed bitmap is all zero between rounds
         lds_order();
         if (JOIN) {                                        // join form: the bitmap says where, not which bucket slot
             const u32 hq = qkL[(u32)qp];
@@ -641,7 +647,7 @@ struct DevWave {
         const int ilim = imin(scan_pos, iend) - NT;             // the queue and the query cover the tracking steps of i <= ilim
         const int rlim = R.len - MSL + 1 - WIN;                 // the seed window of r_end <= rlim is complete
         const u32 ldsb = (u32)(size_t)bitmap;                   // LDS byte offset (low half of the flat address)
-        const u32 scrw = SEED_BM_WORDS + (u32)lane;             // a lane's own scratch word (see seed_prefilter)
+        const u32 scrw = (u32)lane;                             // a lane's own scratch word (see seed_prefilter)
         const u32 zero = 0;
         const u32* const qks = uniform_ptr(qkS);
         const u32* const rks = uniform_ptr(rkS);
@@ -1185,7 +1191,7 @@ __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32
     const int lane = threadIdx.x & 63;
     u32* const lds = s_dyn + (threadIdx.x >> 6) * SEED_LDS_WORDS;
     u32* const flt = s_dyn + BLK_WAVES * SEED_LDS_WORDS;
-    u32* const ctl = s_dyn + SEED_BM_WORDS;        // three words in wave 0's candidate buffer: dead while the block is between segments
+    u32* const ctl = s_dyn;                        // three words of wave 0's seed bitmap while the block is between segments (zeroed before wave 0 goes on)
     for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[k] = 0;
     u32 qx = xcc_id() % NQUEUES, dry = 0;
     for (;;) {
@@ -1226,6 +1232,7 @@ __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32
             }
             if (threadIdx.x == 0) { blkctr[blockIdx.x] = 0; __threadfence(); }
             __syncthreads();
+            if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }       // (every wave has read them before the barrier)
             const u32 n_seg = (u32)(seg_end - cur);
             const u32 j0 = (u32)(base + cur - a.qcum[lo]);
             for (;;) {
