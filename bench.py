@@ -243,10 +243,11 @@ def main():
                                    if world > 1 else "single GPU, all rows",
                        "params": params,
                        "index_form": {"dir_bits": lay["dir_bits"], "tag_words": lay["tag_words"], "bucket_table": lay["bucket_table"],
-                                      "n_free": lay["n_free"], "slots": lay["slots"], "batches_per_step": lay["batches_last_run"]}},
+                                      "n_free": lay["n_free"], "slots": lay["slots"], "batches_per_step": lay["batches_last_run"],
+                                      "block_kernel_with_lds_filter": int(lay["block_launches"] > 0)}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.seed, slab, world),
-                         "kernel": "k_pairs", "avg_launch_ms": avg_launch_ms, "launches": launches,
+                         "kernel": "k_pairs_blk" if lay["block_launches"] else "k_pairs", "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": abytes / launches,
                          "index_build_ms_per_step": index_ms / args.steps},
         }
