@@ -96,7 +96,7 @@ struct lzani_ctx {
     unsigned long long* d_cursor = nullptr;
     u32* d_blkctr = nullptr;      // k_pairs_blk: one pair counter per block
     int blk_launches = 0;         // launches of k_pairs_blk in the last run
-    int blk_fold = -1;            // k_pairs_blk: LDS filter = global filter folded 2^blk_fold times (-1: not decided yet)
+    int blk_fold = -1;            // k_pairs_blk: LDS filter = global filter folded 2^blk_fold times (-1: not decided yet, -2: does not fit)
 
     lzani_timing tm{};
 
@@ -549,6 +549,25 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 #define LZ_PAIRS(F, N, D, A, B) hipLaunchKernelGGL((k_pairs<F, N, D, A, B>), gd, bd, 0, c->stream, pa)
 #define LZ_PAIRS_JOIN(N, D) hipLaunchKernelGGL((k_pairs<true, N, D, false, true, true>), gd, bd, 0, c->stream, pa)
             const bool fast = c->d_kmL != nullptr, tw = pa.tw != nullptr, nf = c->all_nfree;
+            // Probe form, dense rows of hundreds of pairs: blocks of 16 waves with the reference's presence filter in LDS
+            // (k_pairs_blk).  The rows a kmer-db filter leaves hold related pairs, where most positions pass the filter:
+            // BASELINE configs[4] at full size is 6 % slower this way; LZANI_BLOCK_KERNEL=1/0 overrides.
+            bool use_blk = !rs && fast && tw && !pa.skeys && c->fl_stride && (e1 - e0) / rows >= 128 &&
+                           (bkenv ? *bkenv == '1' : query_ids == nullptr);
+            const void* kf = nf ? (defp ? (const void*)k_pairs_blk<true, true> : (const void*)k_pairs_blk<true, false>)
+                                : (defp ? (const void*)k_pairs_blk<false, true> : (const void*)k_pairs_blk<false, false>);
+            if (use_blk && c->blk_fold == -1) {     // the largest LDS copy of the filter that leaves two blocks per CU
+                for (int fold = 0; fold <= 4 && c->blk_fold < 0; ++fold) {
+                    const size_t l = (size_t)(BLK_WAVES * SEED_LDS_WORDS + std::max<u64>(c->fl_stride >> fold, 1)) * 4;
+                    if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l) != hipSuccess) { (void)hipGetLastError(); continue; }
+                    int nb = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf, 64 * BLK_WAVES, l) == hipSuccess && nb >= 2) c->blk_fold = fold;
+                }
+                (void)hipGetLastError();
+                if (c->blk_fold < 0) c->blk_fold = -2;                  // none does: the wave kernel takes these rows too
+            }
+            if (c->blk_fold < 0) use_blk = false;
+            if (use_blk && !c->d_blkctr) HIPCHK(c, hipMalloc(&c->d_blkctr, (size_t)c->n_cus * 2 * 4));
             if (rs) {                                   // alignment output: one generic instantiation per index form
                 if (!fast) LZ_PAIRS(false, false, false, true, false);
                 else if (tw) LZ_PAIRS(true, false, false, true, true);
@@ -559,22 +578,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (nf) LZ_PAIRS_JOIN(true, false);
                 else if (defp) LZ_PAIRS_JOIN(false, true);
                 else LZ_PAIRS_JOIN(false, false);
-            } else if (tw && c->fl_stride && (e1 - e0) / rows >= 128 && (bkenv ? *bkenv == '1' : query_ids == nullptr)) {
-                // probe form, dense rows of hundreds of pairs: blocks of 16 waves with the reference's presence filter in LDS.
-                // (The rows a kmer-db filter leaves hold related pairs, where most positions pass the filter: BASELINE
-                // configs[4] at full size is 6 % slower this way; LZANI_BLOCK_KERNEL=1/0 overrides.)
-                if (!c->d_blkctr) HIPCHK(c, hipMalloc(&c->d_blkctr, (size_t)c->n_cus * 2 * 4));
-                const void* kf = nf ? (defp ? (const void*)k_pairs_blk<true, true> : (const void*)k_pairs_blk<true, false>)
-                                    : (defp ? (const void*)k_pairs_blk<false, true> : (const void*)k_pairs_blk<false, false>);
-                if (c->blk_fold < 0) {              // the largest LDS copy of the filter that leaves two blocks per CU
-                    for (int fold = 0; fold <= 4 && c->blk_fold < 0; ++fold) {
-                        const size_t lds = (size_t)(BLK_WAVES * SEED_LDS_WORDS + std::max<u64>(c->fl_stride >> fold, 1)) * 4;
-                        if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); continue; }
-                        int nb = 0;
-                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kf, 64 * BLK_WAVES, lds) == hipSuccess && nb >= 2) c->blk_fold = fold;
-                    }
-                    if (c->blk_fold < 0) return fail(c, LZANI_ERR_DEVICE, "k_pairs_blk: no LDS configuration with two blocks per CU");
-                }
+            } else if (use_blk) {
                 const u32 fw = (u32)std::max<u64>(c->fl_stride >> c->blk_fold, 1);
                 const size_t lds = (size_t)(BLK_WAVES * SEED_LDS_WORDS + fw) * 4;
                 HIPCHK(c, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1193,7 +1193,7 @@ __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32
     u32* const flt = s_dyn + BLK_WAVES * SEED_LDS_WORDS;
     u32* const ctl = s_dyn;                        // three words of wave 0's seed bitmap while the block is between segments (zeroed before wave 0 goes on)
     for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[k] = 0;
-    u32 qx = xcc_id() % NQUEUES, dry = 0;
+    u32 qx = xcc_id() % NQUEUES, dry = 0, have_slot = 0xFFFFFFFFu;
     for (;;) {
         __syncthreads();                           // (ctl is free: nobody is inside a pair)
         const u32 rb = a.qb[qx], re = a.qb[qx + 1];
@@ -1223,12 +1223,15 @@ __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32
             const u64 seg_end = row_end < t1 ? row_end : t1;
             if (seg_end <= cur) continue;
             const u32 slot = a.qorder[lo];
-            const u32* const gf = a.fl + (u64)slot * a.fl_stride;
-            // (a filter of fwords << fold words folded onto fwords: bit b of the copy = OR of the bits b + i * 32 * fwords)
-            for (u32 k = threadIdx.x; k < fwords; k += 64 * BLK_WAVES) {
-                u32 v = gf[k];
-                for (u32 i = 1; i < (1u << fold); ++i) v |= gf[k + i * fwords];
-                flt[k] = v;
+            if (slot != have_slot) {                // (block-uniform) the LDS copy still holds the filter of the last segment's reference
+                const u32* const gf = a.fl + (u64)slot * a.fl_stride;
+                // (a filter of fwords << fold words folded onto fwords: bit b of the copy = OR of the bits b + i * 32 * fwords)
+                for (u32 k = threadIdx.x; k < fwords; k += 64 * BLK_WAVES) {
+                    u32 v = gf[k];
+                    for (u32 i = 1; i < (1u << fold); ++i) v |= gf[k + i * fwords];
+                    flt[k] = v;
+                }
+                have_slot = slot;
             }
             if (threadIdx.x == 0) { blkctr[blockIdx.x] = 0; __threadfence(); }
             __syncthreads();
