@@ -502,6 +502,9 @@ LZ_HD int popc32(u32 x) { return popc64((u64)x); }
 //   bit 30        the first aw backward symbols hold more than am mismatches (the scan breaks inside them)
 //   bit 31        the forward extension is provably empty: its first aw symbols break the scan and none qualifies up to
 //                 the break
+//   aw <= 15 and bit 30 set: the backward scan breaks inside its first aw symbols, so -- given that the machine may look
+//                 at least aw symbols back -- its result is state-free too; the low bits then hold, instead of the qual
+//                 bits: bits 0..3 its length b (0 = empty), bits 4..7 the matches among its b symbols
 //   aw <= 15 only (the bits above the qual bits are free):
 //   bit 29        the forward extension is KNOWN: its first aw symbols break the scan (at the (am+1)-th mismatch, since
 //                 every window up to there starts at the match), so it ends at the last qualifying symbol before the break:
@@ -525,7 +528,16 @@ LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q,
     u32 rec = ext_rec_none(P.aw);
     if (qp >= 32 && pos >= 32) {                                       // all 32 symbols before the match exist
         const u32 Bb = brev32(lane_mism32(R, Q, qp - 32, pos - 32));   // bit j = symbol qp-1-j / pos-1-j
-        rec = (ext_qual32(Bb, P.ar) & wm) | (popc32(Bb & wm) > P.am ? (u32)EXT_REC_BRKB : 0u);
+        const u32 qb = ext_qual32(Bb, P.ar) & wm;
+        if (popc32(Bb & wm) <= P.am) rec = qb;
+        else if (P.aw > 15) rec = qb | EXT_REC_BRKB;
+        else {                                                          // the scan breaks at the (am+1)-th mismatch
+            u32 x = Bb & wm;
+            for (int k = 0; k < P.am; ++k) x &= x - 1u;
+            const u32 q = qb & (u32)lowmask((int)__builtin_ctz(x) + 1);
+            const int b = q ? 32 - (int)__builtin_clz(q) : 0;            // ends at the last qualifying symbol
+            rec = (u32)b | ((u32)(b - popc32(Bb & (u32)lowmask(b))) << 4) | EXT_REC_BRKB;
+        }
     }
     const int fq = qp + al, fr = pos + al;
     if (imin(Q.len - fq, R.len - fr) >= P.aw) {
@@ -548,8 +560,16 @@ LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q,
 LZ_HD bool ext_rec_null_bwd(u32 rec, int reach, int aw)
 {
     if (reach <= 0) return true;
+    if (aw <= 15 && (rec & EXT_REC_BRKB)) return reach >= aw && (rec & 15u) == 0;    // the scan's own result (full first window)
     const int m = imin(imin(reach, aw), 30);                    // 1 .. 30 (aw > 30: the record has every qual bit set)
     return (rec & ((1u << m) - 1u)) == 0 && (reach <= aw || (rec & EXT_REC_BRKB));
+}
+// the backward extension is in the record (aw <= 15): its length b > 0 and the matches c among its b symbols
+LZ_HD bool ext_rec_bwd_known(u32 rec, int reach, int aw, int& b, int& c)
+{
+    if (aw > 15 || !(rec & EXT_REC_BRKB) || reach < aw) return false;
+    b = (int)(rec & 15u); c = (int)((rec >> 4) & 15u);
+    return b > 0;
 }
 
 // ---- the pair state machine ------------------------------------------------------------
@@ -774,7 +794,11 @@ struct PairMachine {
                 const bool fwd_k = have_rec && P.aw <= 15 && (rec & EXT_REC_FWDK);
                 const int fe = fwd_k ? (int)((rec >> 24) & 31u) : 0, fmm = fwd_k ? (int)((rec >> 20) & 15u) : 0;
                 const bool fwd_free = null_f | fwd_k;
-                const bool null_b = nb == 0 || (have_rec && ext_rec_null_bwd(rec, imin(avail, imin(i, bpos)), P.aw));
+                const int reach = imin(avail, imin(i, bpos));
+                const bool null_b = nb == 0 || (have_rec && ext_rec_null_bwd(rec, reach, P.aw));
+                int kb = 0, kc = 0;                                     // the backward extension from the record, if it is there
+                const bool bwd_k = have_rec && !null_b && ext_rec_bwd_known(rec, reach, P.aw, kb, kc);
+                const bool bwd_free = null_b | bwd_k;
                 if (null_f & null_b) {
                     // the null event: no text access, no lane work; the match opens a region on its own
                     g.finalize();                                       // a match_distant factor follows
@@ -785,9 +809,10 @@ struct PairMachine {
                     continue;
                 }
                 int b = 0;
-                if (null_b | fwd_free) {
-                    // one side is known (empty, or the forward extension from the record): fetch and scan the other one only
-                    if (!null_b) { Bb = w.mism_bwd(i, bpos, nb); b = extend_backward(i, bpos, avail, true, Bb); }
+                if (bwd_free | fwd_free) {
+                    // one side is known (empty, or the extension itself from the record): fetch and scan the other one only
+                    if (!bwd_free) { Bb = w.mism_bwd(i, bpos, nb); b = extend_backward(i, bpos, avail, true, Bb); }
+                    else b = kb;
                 } else {
                     // the first chunks of the backward and of the forward extension are fetched together (one
                     // memory wait); the fold of the backward part comes out of the same mask
@@ -800,7 +825,11 @@ struct PairMachine {
                 region_close();
                 if (__builtin_expect(b > 0, 0)) {
                     pre_lit = avail - b;
-                    if (__builtin_expect(b <= nb, 1)) {                 // forward order = the b mask bits reversed
+                    if (bwd_k) {
+                        // = seg(M, b) below, up to how the b - kc literals split between clit and nl -- and the match run
+                        // that follows at once moves nl into clit whatever the split
+                        g.cl += kc; g.clit += g.nl + (b - kc); g.nl = 0;
+                    } else if (__builtin_expect(b <= nb, 1)) {          // forward order = the b mask bits reversed
                         const u64 M = brev64(~Bb & lowmask(b)) >> (64 - b);
                         g.seg(M, b);
                         if (ALN) runs(M, b, i - b, bpos - b, 0);

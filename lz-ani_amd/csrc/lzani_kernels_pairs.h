@@ -651,7 +651,7 @@ struct DevWave {
         const u32 zero = 0;
         const u32* const qks = uniform_ptr(qkS);
         const u32* const rks = uniform_ptr(rkS);
-        int code, ap, rec, t0, t1, t2, qh = q_head;
+        int code, ap, rec, t0, t1, t2, kb, kc, qh = q_head;
         u64 m, seed;
         u32 rk0, rk1, qk, a0, a1, aq, t, bq;
 #ifdef LZANI_CHAIN_STATS
@@ -721,16 +721,24 @@ struct DevWave {
             "s_add_i32 %[t1], %[t1], %[plit]\n\t"           // avail
             "s_min_i32 %[t0], %[t1], %[ap]\n\t"
             "s_min_i32 %[t0], %[t0], %[bpos]\n\t"           // reach
+            "s_mov_b32 %[kb], 0\n\t"                          // the backward extension: empty, unless the record holds it
+            "s_mov_b32 %[kc], 0\n\t"
             "s_cmp_lt_i32 %[t0], 1\n\t"
             "s_cbranch_scc1 Lnc_ok_%=\n\t"
-            "s_min_i32 %[code], %[t0], %[AW]\n\t"
-            "s_bfm_b32 %[code], %[code], 0\n\t"
+            "s_bitcmp1_b32 %[rec], 30\n\t"
+            "s_cbranch_scc1 Lnc_brkb_%=\n\t"
+            "s_min_i32 %[code], %[t0], %[AW]\n\t"           // no break inside the first aw symbols: the qual bits decide,
+            "s_bfm_b32 %[code], %[code], 0\n\t"             // if the machine may not look further back than they reach
             "s_and_b32 %[code], %[code], %[rec]\n\t"
             "s_cbranch_scc1 Lnc_chk_%=\n\t"
             "s_cmp_le_i32 %[t0], %[AW]\n\t"
             "s_cbranch_scc1 Lnc_ok_%=\n\t"
-            "s_bitcmp0_b32 %[rec], 30\n\t"
-            "s_cbranch_scc1 Lnc_chk_%=\n"
+            "s_branch Lnc_chk_%=\n"
+            "Lnc_brkb_%=:\n\t"                               // the scan breaks inside them: its result is in the record
+            "s_cmp_lt_i32 %[t0], %[AW]\n\t"                 // (given the full first window)
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_and_b32 %[kb], %[rec], 15\n\t"
+            "s_bfe_u32 %[kc], %[rec], 0x40004\n"
             "Lnc_ok_%=:\n\t"
             "s_mov_b32 %[t2], 1\n"
             "Lnc_chk_%=:\n\t"
@@ -771,12 +779,15 @@ struct DevWave {
             "s_cmp_eq_u32 %[t2], 0\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the event is found but is not a null event
             // the null event
-            "s_mov_b32 %[plit], %[t1]\n\t"
-            "s_mov_b32 %[prs], %[ap]\n\t"
+            "s_sub_i32 %[plit], %[t1], %[kb]\n\t"           // what is left of the literals before the backward extension
+            "s_sub_i32 %[prs], %[ap], %[kb]\n\t"            // the region starts with it
             "s_bfe_u32 %[t0], %[rec], 0x50018\n\t"          // e: the forward extension's length (bits 24..28)
-            "s_bfe_u32 %[lastlit], %[rec], 0x40014\n\t"     // its mismatches (bits 20..23) = the literals of the open region
+            "s_bfe_u32 %[lastlit], %[rec], 0x40014\n\t"     // its mismatches (bits 20..23)
             "s_add_i32 %[t2], %[blen], %[t0]\n\t"
-            "s_sub_i32 %[lastb], %[t2], %[lastlit]\n\t"     // its matches: the anchor + the extension's
+            "s_sub_i32 %[lastb], %[t2], %[lastlit]\n\t"     // the region's matches: the anchor, the extensions'
+            "s_add_i32 %[lastb], %[lastb], %[kc]\n\t"
+            "s_add_i32 %[lastlit], %[lastlit], %[kb]\n\t"   // and its literals: the extensions' mismatches
+            "s_sub_i32 %[lastlit], %[lastlit], %[kc]\n\t"
             "s_add_i32 %[i], %[ap], %[t2]\n\t"
             "s_add_i32 %[rend], %[bpos], %[t2]\n\t"
             "s_mov_b32 %[pre], %[i]\n\t"
@@ -796,7 +807,7 @@ struct DevWave {
             "s_nop 4"
             : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit),
               [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec),
-              [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [m] "=&s"(m), [seed] "=&s"(seed),
+              [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [m] "=&s"(m), [seed] "=&s"(seed),
               [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq)
             : [qc] "s"(q_cnt), [ilim] "s"(ilim), [rlim] "s"(rlim), [qks] "s"(qks), [rks] "s"(rks),
               [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), [scrw] "v"(scrw),
