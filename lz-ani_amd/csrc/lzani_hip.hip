@@ -322,7 +322,7 @@ int build_join_lists(lzani_ctx* c)
 }
 
 // Index build of `rows` references (device list d_ref_ids) into slots 0..rows-1.
-int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
+int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows, bool with_filter = true)
 {
     IdxArgs ia;
     ia.G = gtab(c);
@@ -343,7 +343,7 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows)
         c->tm.index_launches += 1;
         if (c->join_mode) { int rc = build_join_lists(c); if (rc) return rc; }
     }
-    if (c->fl_stride) {
+    if (c->fl_stride && with_filter) {              // (only the block kernel reads it)
         HIPCHK(c, hipMemsetAsync(c->d_fl, 0, (size_t)rows * c->fl_stride * 4, c->stream));
         hipLaunchKernelGGL(k_idx_filter, dim3((u32)std::min<u64>(((u64)c->Tmax + 255) / 256, 64), rows), dim3(256), 0, c->stream,
                            ia, c->d_fl, c->fl_stride, c->fmask, c->Tmax);
@@ -523,7 +523,10 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         hipEvent_t* ev = c->events.data() + (size_t)4 * b;
         TRACE("batch %u rows [%u,%u) pairs [%llu,%llu) slots=%u", b, k0, k0 + rows, (unsigned long long)e0, (unsigned long long)e1, c->slots);
         HIPCHK(c, hipEventRecord(ev[0], c->stream));
-        rc = build_indexes(c, d_ref + k0, rows);
+        // rows for k_pairs_blk (see below): dense, hundreds of pairs each, probe form with tag words and a filter
+        const bool blk_rows = !rs && c->d_kmL && c->tw_stride && !c->join_mode && c->fl_stride && e1 > e0 && (e1 - e0) / rows >= 128 &&
+                              (bkenv ? *bkenv == '1' : query_ids == nullptr);
+        rc = build_indexes(c, d_ref + k0, rows, blk_rows);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(ev[1], c->stream));
         if (e1 > e0) {
@@ -552,8 +555,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             // Probe form, dense rows of hundreds of pairs: blocks of 16 waves with the reference's presence filter in LDS
             // (k_pairs_blk).  The rows a kmer-db filter leaves hold related pairs, where most positions pass the filter:
             // BASELINE configs[4] at full size is 6 % slower this way; LZANI_BLOCK_KERNEL=1/0 overrides.
-            bool use_blk = !rs && fast && tw && !pa.skeys && c->fl_stride && (e1 - e0) / rows >= 128 &&
-                           (bkenv ? *bkenv == '1' : query_ids == nullptr);
+            bool use_blk = blk_rows && fast && tw && !pa.skeys;
             const void* kf = nf ? (defp ? (const void*)k_pairs_blk<true, true> : (const void*)k_pairs_blk<true, false>)
                                 : (defp ? (const void*)k_pairs_blk<false, true> : (const void*)k_pairs_blk<false, false>);
             if (use_blk && c->blk_fold == -1) {     // the largest LDS copy of the filter that leaves two blocks per CU
