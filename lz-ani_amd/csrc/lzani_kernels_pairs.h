@@ -1107,7 +1107,11 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
     iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
     const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
+#ifdef LZANI_STAMPS
+    constexpr bool CHAIN = false;                   // (the diagnostic build times the compiler's own sections)
+#else
     constexpr bool CHAIN = FAST && BK && DEFP && !ALN;
+#endif
     DevWave<FAST, BK, JOIN, CHAIN, LFLT> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                     qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
                     lds,
