@@ -63,6 +63,11 @@ typedef struct lzani_timing {
     uint32_t pair_launches;     /* number of pair-kernel launches (= batches)               */
     uint32_t index_launches;    /* number of index-build kernel launches                    */
     uint64_t pairs;             /* directed pairs processed                                 */
+    double   cand_ms;           /* sum over batches: presence matrix + candidate bitmaps of dense rows (0 otherwise) */
+    double   kmers_ms;          /* per-genome k-mer words (+ join lists): made by the first run after
+                                 * lzani_set_genomes and kept; 0 in the runs that found them ready; not part of index_ms */
+    uint32_t cand_launches;     /* kernel launches of the candidate stage                   */
+    uint32_t reserved_;
 } lzani_timing;
 
 /* One region of CParser::calc_regions / get_parsing (/root/reference/src/parser.cpp:786-837,
@@ -130,6 +135,9 @@ typedef struct lzani_layout_info {
     int32_t  join_lists;                    /* 1: candidates come from a join with per-genome sorted k-mer lists (long genomes) */
     int32_t  block_launches;                /* pair-kernel launches of the last run by blocks of 16 waves with the
                                              * reference's presence filter in LDS (probe form, rows of >= 128 pairs) */
+    int32_t  bitmap_launches;               /* pair-kernel launches of the last run fed by per-pair candidate bitmaps
+                                             * (dense rows: presence matrix of the batch's references)                 */
+    int32_t  reserved_;
 } lzani_layout_info;
 int lzani_get_layout(const lzani_ctx *ctx, lzani_layout_info *info);
 

@@ -2,6 +2,7 @@
 //
 // The kernels (all integer / bit work; no MFMA by design) live in two headers included below:
 //   lzani_kernels_index.h   k_pack, k_kmers, k_idx_*   genomes -> packed texts, k-mer words, anchor indexes
+//   lzani_kernels_cand.h    k_pm_build, k_pm_cand   dense rows: presence matrix of a group of references -> per-pair candidate bitmaps
 //   lzani_kernels_pairs.h   DevWave, k_pairs   the pair kernel
 // The algorithm itself (PairMachine and its building blocks, shared with the host model of the tests) is
 // lzani_core.h; sizes and the parameter envelope are lzani_layout.h.
@@ -31,6 +32,7 @@ int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_
 #include "lzani_core.h"
 #include "lzani_layout.h"
 #include "lzani_kernels_index.h"
+#include "lzani_kernels_cand.h"
 #include "lzani_kernels_pairs.h"
 
 // ============================================================================================
@@ -60,6 +62,8 @@ struct lzani_ctx {
     u32* d_kmS = nullptr;
     u64 total_nm = 0;
     bool kmers_ready = false;
+    bool km_timed = false;        // the last run made the k-mer words (ev_km holds their stamps)
+    hipEvent_t ev_km[2] = {nullptr, nullptr};
     bool all_nfree = false;       // no genome holds an N: the NFREE kernel instantiation applies
 
     u32* d_dirz = nullptr;
@@ -97,6 +101,13 @@ struct lzani_ctx {
     u32* d_blkctr = nullptr;      // k_pairs_blk: one pair counter per block
     int blk_launches = 0;         // launches of k_pairs_blk in the last run
     int blk_fold = -1;            // k_pairs_blk: LDS filter = global filter folded 2^blk_fold times (-1: not decided yet, -2: does not fit)
+    // dense rows: candidates from the presence matrix of a group of references (lzani_kernels_cand.h)
+    u32* d_pm = nullptr;          // the matrix of one group: 2^pm_bits rows of PM_GROUP bits
+    size_t pm_bytes = 0;
+    u32* d_pm_cbits = nullptr;    // candidate bitmaps of a batch's pairs
+    size_t pm_cbits_bytes = 0;
+    int pm_launches = 0;          // pair-kernel launches of the last run fed by candidate bitmaps
+    bool pm_attr_set = false;
 
     lzani_timing tm{};
 
@@ -152,6 +163,8 @@ void free_genomes(lzani_ctx* c)
 }
 void free_slabs(lzani_ctx* c)
 {
+    hipFree(c->d_pm); hipFree(c->d_pm_cbits);
+    c->d_pm = c->d_pm_cbits = nullptr; c->pm_bytes = c->pm_cbits_bytes = 0;
     hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_bk); hipFree(c->d_tw); hipFree(c->d_fl); hipFree(c->d_status);
     c->d_fl = nullptr;
     hipFree(c->d_ikeys_in); hipFree(c->d_ikeys); hipFree(c->d_icnt); hipFree(c->d_ibase);
@@ -248,14 +261,19 @@ GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmo
 int alloc_join_lists(lzani_ctx* c)
 {
     const u32 n = c->n;
-    if (c->d_jkoff) return LZANI_OK;
+    if (c->d_jkeys) return LZANI_OK;                 // (set last: a partial allocation is released below and redone)
     c->jkoff.assign((size_t)n + 1, 0);
     for (u32 g = 0; g < n; ++g) c->jkoff[g + 1] = c->jkoff[g] + (u64)c->L[g];
-    HIPCHK(c, hipMalloc(&c->d_jkoff, ((size_t)n + 1) * 8));
-    HIPCHK(c, hipMalloc(&c->d_jsoff, ((size_t)n + 1) * 8));
-    HIPCHK(c, hipMalloc(&c->d_jcnt, (size_t)n * 4));
-    HIPCHK(c, hipMalloc(&c->d_jkeys, std::max<u64>(c->jkoff[n], 1) * 8));
-    HIPCHK(c, hipMemcpyAsync(c->d_jkoff, c->jkoff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = hipMalloc(&c->d_jkoff, ((size_t)n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&c->d_jsoff, ((size_t)n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&c->d_jcnt, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&c->d_jkeys, std::max<u64>(c->jkoff[n], 1) * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_jkoff, c->jkoff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        hipFree(c->d_jkoff); hipFree(c->d_jsoff); hipFree(c->d_jcnt); hipFree(c->d_jkeys);
+        c->d_jkoff = c->d_jsoff = nullptr; c->d_jcnt = nullptr; c->d_jkeys = nullptr;
+        return fail(c, e == hipErrorOutOfMemory ? LZANI_ERR_NOMEM : LZANI_ERR_DEVICE, std::string("join lists: ") + hipGetErrorString(e));
+    }
     return LZANI_OK;
 }
 
@@ -321,6 +339,30 @@ int build_join_lists(lzani_ctx* c)
     return LZANI_OK;
 }
 
+// Per-genome k-mer words (and, for long genomes, the sorted join lists made from them): once per genome set, by the
+// first run after lzani_set_genomes -- before its index slabs are sized, so that the slabs see what the lists and the
+// sort's temporaries have left -- and kept for the runs that follow (they depend on the genomes and the parameters
+// only).  Timed on their own (lzani_timing.kmers_ms).
+int ensure_kmers(lzani_ctx* c)
+{
+    if (!c->d_kmL || c->kmers_ready) return LZANI_OK;
+    HIPCHK(c, hipEventRecord(c->ev_km[0], c->stream));
+    for (u32 g0 = 0; g0 < c->n; g0 += 32768) {
+        u32 cnt = std::min<u32>(32768, c->n - g0);
+        GenomeTab G = gtab(c);
+        G.nmoff += g0; G.L += g0;
+        hipLaunchKernelGGL(k_kmers, dim3((c->Tmax + 255) / 256, cnt), dim3(256), 0, c->stream,
+                           G, c->d_kmL, c->d_kmS, c->P.mal, c->P.msl, c->P.mrd, c->Tmax);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->tm.index_launches += 1;
+    if (c->join_mode) { int rc = build_join_lists(c); if (rc) return rc; }
+    HIPCHK(c, hipEventRecord(c->ev_km[1], c->stream));
+    c->kmers_ready = true;
+    c->km_timed = true;
+    return LZANI_OK;
+}
+
 // Index build of `rows` references (device list d_ref_ids) into slots 0..rows-1.
 int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows, bool with_filter = true)
 {
@@ -331,18 +373,7 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows, bool with_filter
     ia.dir_stride = c->dir_stride; ia.ent_stride = c->ent_stride;
     ia.mal = c->P.mal; ia.mrd = c->P.mrd; ia.geo = c->geo; ia.todo = nullptr;
     const u32 nb = 1u << c->geo.dirbits;
-    if (c->d_kmL && !c->kmers_ready) {            // per-genome k-mer words, inside the timed index stage
-        for (u32 g0 = 0; g0 < c->n; g0 += 32768) {
-            u32 cnt = std::min<u32>(32768, c->n - g0);
-            GenomeTab G = gtab(c);
-            G.nmoff += g0; G.L += g0;
-            hipLaunchKernelGGL(k_kmers, dim3((c->Tmax + 255) / 256, cnt), dim3(256), 0, c->stream,
-                               G, c->d_kmL, c->d_kmS, c->P.mal, c->P.msl, c->P.mrd, c->Tmax);
-        }
-        c->kmers_ready = true;
-        c->tm.index_launches += 1;
-        if (c->join_mode) { int rc = build_join_lists(c); if (rc) return rc; }
-    }
+    { int rc = ensure_kmers(c); if (rc) return rc; }
     if (c->fl_stride && with_filter) {              // (only the block kernel reads it)
         HIPCHK(c, hipMemsetAsync(c->d_fl, 0, (size_t)rows * c->fl_stride * 4, c->stream));
         hipLaunchKernelGGL(k_idx_filter, dim3((u32)std::min<u64>(((u64)c->Tmax + 255) / 256, 64), rows), dim3(256), 0, c->stream,
@@ -419,9 +450,11 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 {
     if (!c->n) return fail(c, LZANI_ERR_STATE, "lzani_run_rows: no genomes set");
     c->tm = lzani_timing{};
-    c->kmers_ready = false;                       // recomputed inside every run: it is part of the path's work
+    // (the k-mer words and the join lists are made by the first run after lzani_set_genomes -- inside its timed index
+    // stage, reported as kmers_ms -- and kept: they depend on the genome set and the parameters only)
     c->batches_last_run = 0;
     c->blk_launches = 0;
+    c->pm_launches = 0;
     if (n_rows == 0) return LZANI_OK;
     const u64 n_pairs = row_off[n_rows];
     for (u32 k = 0; k < n_rows; ++k) {
@@ -437,15 +470,63 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     if (n_pairs == 0) return LZANI_OK;
 
     HIPCHK(c, hipSetDevice(c->dev));
-    int rc = c->join_mode ? alloc_join_lists(c) : LZANI_OK;
+    c->km_timed = false;
+    int rc = ensure_kmers(c);
     if (rc) return rc;
     rc = ensure_slabs(c, n_rows);
     if (rc) return rc;
 
-    // Batches of `slots` rows (one index slab per row).  Everything the batches need from the host -- row tables
+    // Dense rows: the candidates of every pair of a batch come from the presence matrix of its references
+    // (lzani_kernels_cand.h) instead of a probe per query position; a batch is then also bounded by what the candidate
+    // bitmaps of its pairs take.
+    u32 bs = c->slots;                                       // rows per batch
+    bool pm = false;
+    u64 cb_words = 0;                                        // 32-bit words of one pair's candidate bitmap
+    u32 pm_tiles = 0;
+    const int pm_bits = std::min(c->geo.kb, 24);
+    {
+        const char* e = getenv("LZANI_PM");
+        const char* mn = getenv("LZANI_PM_MIN_ROWS");
+        const char* mb = getenv("LZANI_PM_MAX_BYTES");
+        const u32 min_rows = mn ? (u32)std::max(1, atoi(mn)) : 32u;
+        pm = !rs && !query_ids && c->d_kmL && c->tw_stride && !c->join_mode && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 24 &&
+             c->n >= 2 && n_rows >= min_rows && !(e && *e == '0');
+        if (pm) {
+            int Lmax = 0;
+            for (u32 g = 0; g < c->n; ++g) Lmax = std::max(Lmax, c->L[g]);
+            pm_tiles = (u32)(((u64)Lmax + c->P.mrd + 320 + PM_TILE - 1) / PM_TILE);
+            cb_words = (u64)pm_tiles * PM_TILE_WORDS;
+            const size_t m_bytes = ((size_t)1 << pm_bits) * (PM_GROUP / 8);
+            if (c->pm_bytes < m_bytes) {
+                hipFree(c->d_pm); c->d_pm = nullptr; c->pm_bytes = 0;
+                HIPCHK(c, hipMalloc(&c->d_pm, m_bytes));
+                c->pm_bytes = m_bytes;
+            }
+            const size_t per_row = (size_t)(c->n - 1) * cb_words * 4;
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+            const size_t cap = mb ? (size_t)strtoull(mb, nullptr, 10) : ((size_t)32 << 30);
+            const size_t budget = std::min(cap, (size_t)((free_b + c->pm_cbits_bytes) * 0.7));
+            u64 fit = budget / per_row;
+            fit = std::min<u64>(fit, 0xFFFFFFF0ull / (u64)(c->n - 1));             // pair indexes of a batch are 32 bits
+            if (fit < 8) pm = false;                          // (a genome set this large: the probe form, batch by batch)
+            else {
+                bs = (u32)std::min<u64>(bs, fit);
+                if (bs > PM_GROUP) bs -= bs % PM_GROUP;       // whole groups
+                const size_t need = (size_t)std::min(bs, n_rows) * per_row;
+                if (c->pm_cbits_bytes < need) {
+                    hipFree(c->d_pm_cbits); c->d_pm_cbits = nullptr; c->pm_cbits_bytes = 0;
+                    HIPCHK(c, hipMalloc(&c->d_pm_cbits, need));
+                    c->pm_cbits_bytes = need;
+                }
+            }
+        }
+    }
+
+    // Batches of `bs` rows (one index slab per row).  Everything the batches need from the host -- row tables
     // and the per-XCD work queues of every batch -- is prepared and uploaded before the first launch, so the
     // batches follow each other on the stream without a host round trip in between.
-    const u32 n_batches = (n_rows + c->slots - 1) / c->slots;
+    const u32 n_batches = (n_rows + bs - 1) / bs;
     c->batches_last_run = n_batches;
     std::vector<u32> qorder(n_rows);
     std::vector<u64> qcum((size_t)n_rows + n_batches);
@@ -453,8 +534,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     {
         std::vector<u32> by_size;
         std::vector<u32> queue[NQUEUES];
-        for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += c->slots) {
-            const u32 rows = std::min(c->slots, n_rows - k0);
+        for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += bs) {
+            const u32 rows = std::min(bs, n_rows - k0);
             auto rlen = [&](u32 k) { return row_off[k0 + k + 1] - row_off[k0 + k]; };
             // rows -> queues: longest row first onto the least loaded queue (equal rows: round robin)
             by_size.resize(rows);
@@ -495,7 +576,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         HIPCHK(c, d_q.alloc(n_pairs));
         HIPCHK(c, hipMemcpyAsync(d_q, query_ids, (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     }
-    while (c->events.size() < (size_t)4 * n_batches) {        // four stamps per batch, read back after the one sync
+    enum { EV = 5 };
+    while (c->events.size() < (size_t)EV * n_batches) {       // five stamps per batch, read back after the one sync
         hipEvent_t e;
         HIPCHK(c, hipEventCreate(&e));
         c->events.push_back(e);
@@ -517,18 +599,55 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         HIPCHK(c, d_cbits.alloc((size_t)max_blocks * 4 * cbits_stride));
     }
 
-    for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += c->slots) {
-        const u32 rows = std::min(c->slots, n_rows - k0);
+    for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += bs) {
+        const u32 rows = std::min(bs, n_rows - k0);
         const u64 e0 = row_off[k0], e1 = row_off[k0 + rows];
-        hipEvent_t* ev = c->events.data() + (size_t)4 * b;
-        TRACE("batch %u rows [%u,%u) pairs [%llu,%llu) slots=%u", b, k0, k0 + rows, (unsigned long long)e0, (unsigned long long)e1, c->slots);
+        hipEvent_t* ev = c->events.data() + (size_t)EV * b;
+        TRACE("batch %u rows [%u,%u) pairs [%llu,%llu) slots=%u pm=%d", b, k0, k0 + rows, (unsigned long long)e0, (unsigned long long)e1, bs, (int)pm);
         HIPCHK(c, hipEventRecord(ev[0], c->stream));
         // rows for k_pairs_blk (see below): dense, hundreds of pairs each, probe form with tag words and a filter
-        const bool blk_rows = !rs && c->d_kmL && c->tw_stride && !c->join_mode && c->fl_stride && e1 > e0 && (e1 - e0) / rows >= 128 &&
+        const bool blk_rows = !pm && !rs && c->d_kmL && c->tw_stride && !c->join_mode && c->fl_stride && e1 > e0 && (e1 - e0) / rows >= 128 &&
                               (bkenv ? *bkenv == '1' : query_ids == nullptr);
         rc = build_indexes(c, d_ref + k0, rows, blk_rows);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(ev[1], c->stream));
+        if (pm && e1 > e0) {
+            // candidate bitmaps of the batch's pairs, group by group of PM_GROUP references
+            for (u32 g0 = 0; g0 < rows; g0 += PM_GROUP) {
+                PmArgs pg;
+                pg.G = gtab(c);
+                pg.ref_ids = d_ref + k0; pg.row_off = d_off + k0;
+                pg.slot0 = g0; pg.rows = std::min<u32>(PM_GROUP, rows - g0);
+                pg.M = c->d_pm; pg.rw = ((pg.rows + 127) / 128) * 4; pg.mmask = (u32)lowmask(pm_bits);
+                pg.mal = c->P.mal; pg.mrd = c->P.mrd;
+                pg.cbits = c->d_pm_cbits; pg.cb_words = cb_words; pg.e0 = e0; pg.n = c->n; pg.q0 = 0;
+                HIPCHK(c, hipMemsetAsync(c->d_pm, 0, ((size_t)1 << pm_bits) * pg.rw * 4, c->stream));
+                hipLaunchKernelGGL(k_pm_build, dim3((u32)std::min<u64>(((u64)c->Tmax + 255) / 256, 64), pg.rows), dim3(256), 0, c->stream, pg, c->Tmax);
+                const u32 rp = 32 * pg.rw;
+                const size_t lds = (size_t)(PM_TILE_WORDS * (rp + 1) + rp) * 4;
+                if (!c->pm_attr_set) {
+                    const size_t lmax = (size_t)(PM_TILE_WORDS * (PM_GROUP + 1) + PM_GROUP) * 4;
+                    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pm_cand<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmax));
+                    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pm_cand<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmax));
+                    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pm_cand<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmax));
+                    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pm_cand<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmax));
+                    c->pm_attr_set = true;
+                }
+                for (u32 q0 = 0; q0 < c->n; q0 += 32768) {     // gridDim.y is limited to 65535
+                    pg.q0 = q0;
+                    const dim3 gc(pm_tiles, std::min<u32>(32768, c->n - q0)), bc(256);
+                    switch (pg.rw / 4) {
+                    case 1: hipLaunchKernelGGL(k_pm_cand<1>, gc, bc, lds, c->stream, pg); break;
+                    case 2: hipLaunchKernelGGL(k_pm_cand<2>, gc, bc, lds, c->stream, pg); break;
+                    case 3: hipLaunchKernelGGL(k_pm_cand<3>, gc, bc, lds, c->stream, pg); break;
+                    default: hipLaunchKernelGGL(k_pm_cand<4>, gc, bc, lds, c->stream, pg); break;
+                    }
+                }
+                c->tm.cand_launches += 2;
+            }
+            HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipEventRecord(ev[4], c->stream));
         if (e1 > e0) {
             PairArgs pa;
             pa.G = gtab(c);
@@ -543,14 +662,16 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.qorder = d_qorder + k0; pa.qcum = d_qcum + k0 + b;
             for (int x = 0; x <= NQUEUES; ++x) pa.qb[x] = qb[(size_t)b * (NQUEUES + 1) + x];
             pa.skeys = cbits_stride ? c->d_jkeys : nullptr; pa.soff = c->d_jsoff; pa.scnt = c->d_jcnt;
-            pa.cbits = d_cbits.p; pa.cbits_stride = cbits_stride;
+            pa.cbits = d_cbits.p; pa.cbits_stride = cbits_stride; pa.cb_e0 = 0;
+            if (pm) { pa.cbits = reinterpret_cast<unsigned long long*>(c->d_pm_cbits); pa.cbits_stride = cb_words / 2; pa.cb_e0 = e0; }
             pa.reg_out = rs ? rs->d_regions : nullptr; pa.reg_count = rs ? rs->d_count : nullptr; pa.reg_cap = rs ? rs->capacity : 0;
             HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, NQUEUES * sizeof(unsigned long long), c->stream));
             const u64 waves = e1 - e0;
             const dim3 gd((u32)std::min<u64>((waves + 3) / 4, max_blocks)), bd(256);
             HIPCHK(c, hipEventRecord(ev[2], c->stream));
 #define LZ_PAIRS(F, N, D, A, B) hipLaunchKernelGGL((k_pairs<F, N, D, A, B>), gd, bd, 0, c->stream, pa)
-#define LZ_PAIRS_JOIN(N, D) hipLaunchKernelGGL((k_pairs<true, N, D, false, true, true>), gd, bd, 0, c->stream, pa)
+#define LZ_PAIRS_JOIN(N, D) hipLaunchKernelGGL((k_pairs<true, N, D, false, true, 1>), gd, bd, 0, c->stream, pa)
+#define LZ_PAIRS_PM(N, D) hipLaunchKernelGGL((k_pairs<true, N, D, false, true, 2>), gd, bd, 0, c->stream, pa)
             const bool fast = c->d_kmL != nullptr, tw = pa.tw != nullptr, nf = c->all_nfree;
             // Probe form, dense rows of hundreds of pairs: blocks of 16 waves with the reference's presence filter in LDS
             // (k_pairs_blk).  The rows a kmer-db filter leaves hold related pairs, where most positions pass the filter:
@@ -575,7 +696,13 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (tw) LZ_PAIRS(true, false, false, true, true);
                 else LZ_PAIRS(true, false, false, true, false);
             } else if (!fast) LZ_PAIRS(false, false, false, false, false);
-            else if (tw && pa.skeys) {                  // long genomes: candidates by the join
+            else if (pm) {                              // dense rows: candidate bitmaps made ahead (k_pm_cand)
+                c->pm_launches += 1;
+                if (nf && defp) LZ_PAIRS_PM(true, true);
+                else if (nf) LZ_PAIRS_PM(true, false);
+                else if (defp) LZ_PAIRS_PM(false, true);
+                else LZ_PAIRS_PM(false, false);
+            } else if (tw && pa.skeys) {                // long genomes: candidates by the join
                 if (nf && defp) LZ_PAIRS_JOIN(true, true);
                 else if (nf) LZ_PAIRS_JOIN(true, false);
                 else if (defp) LZ_PAIRS_JOIN(false, true);
@@ -602,6 +729,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (defp) LZ_PAIRS(true, false, true, false, false);
                 else LZ_PAIRS(true, false, false, false, false);
             }
+#undef LZ_PAIRS_PM
 #undef LZ_PAIRS_JOIN
 #undef LZ_PAIRS
             HIPCHK(c, hipGetLastError());
@@ -645,11 +773,18 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_guard_trip), &zero, sizeof(int)));
         return fail(c, LZANI_ERR_DEVICE, "pair kernel: loop guard " + std::to_string(trip) + " tripped (corrupt index or text)");
     }
+    if (c->km_timed) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_km[0], c->ev_km[1]));
+        c->tm.kmers_ms = ms;
+    }
     for (u32 b = 0; b < n_batches; ++b) {
-        hipEvent_t* ev = c->events.data() + (size_t)4 * b;
+        hipEvent_t* ev = c->events.data() + (size_t)EV * b;
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, ev[0], ev[1]));
         c->tm.index_ms += ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, ev[1], ev[4]));
+        c->tm.cand_ms += ms;
         if (launched[b]) {
             HIPCHK(c, hipEventElapsedTime(&ms, ev[2], ev[3]));
             c->tm.pairs_ms += ms;
@@ -685,6 +820,7 @@ int lzani_create(const lzani_params* p, int device_id, lzani_ctx** out)
     c->dev = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
               hipMalloc(&c->d_cursor, NQUEUES * sizeof(unsigned long long)) == hipSuccess;
+    if (ok) ok = hipEventCreate(&c->ev_km[0]) == hipSuccess && hipEventCreate(&c->ev_km[1]) == hipSuccess;
     if (ok) {
         hipDeviceProp_t prop;
         ok = hipGetDeviceProperties(&prop, device_id) == hipSuccess;
@@ -705,6 +841,7 @@ void lzani_destroy(lzani_ctx* c)
     hipFree(c->d_cursor);
     hipFree(c->d_blkctr);
     for (auto& e : c->events) if (e) hipEventDestroy(e);
+    for (auto& e : c->ev_km) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -882,7 +1019,7 @@ int lzani_get_layout(const lzani_ctx* c, lzani_layout_info* o)
     o->slots = c->slots; o->batches_last_run = c->batches_last_run;
     o->bytes_per_slot = 4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride);
     o->bytes_genomes = c->total_nm * (16 + 8) + (c->d_kmL ? c->total_nm * 64 * 8 : 0);
-    o->join_lists = c->join_mode; o->block_launches = c->blk_launches;
+    o->join_lists = c->join_mode; o->block_launches = c->blk_launches; o->bitmap_launches = c->pm_launches; o->reserved_ = 0;
     return LZANI_OK;
 }
 

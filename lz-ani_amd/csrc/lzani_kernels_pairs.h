@@ -1061,8 +1061,9 @@ struct PairArgs {
     const unsigned long long* skeys;
     const u64* soff;                 // begin of genome g's sorted keys
     const u32* scnt;                 // their number
-    unsigned long long* cbits;
+    unsigned long long* cbits;       // CAND 1: one bitmap per resident wave; CAND 2: one per pair of the batch, from pair cb_e0 on
     u64 cbits_stride;
+    u64 cb_e0;
     lzani_region* reg_out;        // alignment instantiation only
     unsigned long long* reg_count;
     unsigned long long reg_cap;
@@ -1082,9 +1083,13 @@ __device__ __forceinline__ u32 xcc_id()
 // JOIN = candidates by a join with sorted k-mer lists (long genomes; needs FAST and BK).
 // One pair: row `lo` of the batch's queue order, its j-th query.  `flt` = the block's LDS copy of the reference's
 // presence filter (LFLT instantiations).
-template <bool FAST, bool NFREE, bool DEFP, bool ALN, bool BK, bool JOIN, bool LFLT>
+// CAND: where the anchor candidates of a pair come from -- 0 = a probe per query position (refill), 1 = the wave's own
+// join with the query's sorted k-mer list (long genomes), 2 = the pair's candidate bitmap made ahead by k_pm_cand
+// (dense rows, lzani_kernels_cand.h); 1 and 2 share the bitmap form of refill (DevWave's JOIN).
+template <bool FAST, bool NFREE, bool DEFP, bool ALN, bool BK, int CAND, bool LFLT>
 __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int lane, u32* lds, const u32* flt)
 {
+    constexpr bool JOIN = CAND != 0;
     const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
     const u32 slot = a.qorder[lo];
     const u32 r = a.ref_ids[slot];
@@ -1092,7 +1097,8 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     const u32 q = a.query_ids ? a.query_ids[e] : j + (j >= r ? 1u : 0u);
 
     unsigned long long* cand_bits = nullptr;
-    if (JOIN) {
+    if (CAND == 2) cand_bits = a.cbits + (e - a.cb_e0) * a.cbits_stride;
+    if (CAND == 1) {
         cand_bits = a.cbits + (u64)(blockIdx.x * 4 + (threadIdx.x >> 6)) * a.cbits_stride;
         join_candidates(a.tw + slot * a.tw_stride, a.geo.kb, a.geo.dirbits, a.geo.posbits, a.geo.tagmask,
                         a.skeys + a.soff[q], a.scnt[q], cand_bits, ((a.G.L[q] + (DEFP ? 40 : a.P.mrd)) >> 6) + 8, lane);
@@ -1159,7 +1165,7 @@ __device__ __forceinline__ u32 row_of_ticket(const u64* __restrict__ qcum, u32 r
 // defaults (params.h:34-48), folded into the code as constants.
 // ALN = also emit the regions of every pair (--out-alignment).
 // JOIN = candidates by a join with sorted k-mer lists (long genomes; needs FAST and BK).
-template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false, bool JOIN = false>
+template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false, int CAND = 0>
 __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -1184,7 +1190,7 @@ __global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
             continue;
         }
         const u32 lo = row_of_ticket(a.qcum, rb, re, tk);
-        pair_body<FAST, NFREE, DEFP, ALN, BK, JOIN, false>(a, lo, (u32)(tk - a.qcum[lo]), lane, lds, nullptr);
+        pair_body<FAST, NFREE, DEFP, ALN, BK, CAND, false>(a, lo, (u32)(tk - a.qcum[lo]), lane, lds, nullptr);
     }
 }
 
@@ -1258,7 +1264,7 @@ __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32
                 if (lane == 0) k = atomicAdd(&blkctr[blockIdx.x], 1u);
                 k = __builtin_amdgcn_readfirstlane(k);
                 if (k >= n_seg) break;
-                pair_body<true, NFREE, DEFP, false, true, false, true>(a, lo, j0 + k, lane, lds, flt);
+                pair_body<true, NFREE, DEFP, false, true, 0, true>(a, lo, j0 + k, lane, lds, flt);
             }
             __syncthreads();                       // the filter and the counter are free again
             cur = seg_end;

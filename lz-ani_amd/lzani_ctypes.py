@@ -39,20 +39,22 @@ class LzaniError(RuntimeError):
 
 class Timing(C.Structure):
     _fields_ = [("index_ms", C.c_double), ("pairs_ms", C.c_double), ("pair_launches", C.c_uint32),
-                ("index_launches", C.c_uint32), ("pairs", C.c_uint64)]
+                ("index_launches", C.c_uint32), ("pairs", C.c_uint64), ("cand_ms", C.c_double), ("kmers_ms", C.c_double),
+                ("cand_launches", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class LayoutInfo(C.Structure):
     _fields_ = [("key_bits", C.c_int32), ("dir_bits", C.c_int32), ("pos_bits", C.c_int32), ("tag_mask", C.c_uint32),
                 ("kmer_words", C.c_int32), ("bucket_table", C.c_int32), ("tag_words", C.c_int32), ("n_free", C.c_int32),
                 ("slots", C.c_uint32), ("batches_last_run", C.c_uint32), ("bytes_per_slot", C.c_uint64),
-                ("bytes_genomes", C.c_uint64), ("join_lists", C.c_int32), ("block_launches", C.c_int32)]
+                ("bytes_genomes", C.c_uint64), ("join_lists", C.c_int32), ("block_launches", C.c_int32),
+                ("bitmap_launches", C.c_int32), ("reserved_", C.c_int32)]
 
 
 def build_library(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     deps = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("lzani_core.h", "lzani_layout.h", "lzani_kernels_index.h",
-                                                             "lzani_kernels_pairs.h", "lzani_multi.h", "lzani_sort.hip")] + [os.path.join(ROOT, "include", "lzani.h")]
+                                                             "lzani_kernels_cand.h", "lzani_kernels_pairs.h", "lzani_multi.h", "lzani_sort.hip")] + [os.path.join(ROOT, "include", "lzani.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -199,7 +201,8 @@ class Group:
         t = Timing()
         g = C.c_double(0)
         self._check(self.lib.lzani_group_get_timing(self.h, device_index, C.byref(t), C.byref(g)), "lzani_group_get_timing")
-        return dict(index_ms=t.index_ms, pairs_ms=t.pairs_ms, pair_launches=t.pair_launches, pairs=t.pairs, gather_ms=g.value)
+        return dict(index_ms=t.index_ms, pairs_ms=t.pairs_ms, pair_launches=t.pair_launches, pairs=t.pairs, gather_ms=g.value,
+                    cand_ms=t.cand_ms, kmers_ms=t.kmers_ms)
 
 
 class Engine:
@@ -305,7 +308,8 @@ class Engine:
         t = Timing()
         self._check(self.lib.lzani_get_timing(self.h, C.byref(t)), "lzani_get_timing")
         return dict(index_ms=t.index_ms, pairs_ms=t.pairs_ms, pair_launches=t.pair_launches,
-                    index_launches=t.index_launches, pairs=t.pairs)
+                    index_launches=t.index_launches, pairs=t.pairs, cand_ms=t.cand_ms, kmers_ms=t.kmers_ms,
+                    cand_launches=t.cand_launches)
 
     def layout(self):
         o = LayoutInfo()

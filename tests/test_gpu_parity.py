@@ -474,7 +474,10 @@ def test_full_size_10k_genomes():
     flat = eng.run_rows(ref_ids, row_off, None).reshape(n, n - 1, 3)
     lay = eng.layout()
     eng.close()
-    assert lay["tag_words"] == 1 and lay["n_free"] == 1 and lay["batches_last_run"] == 1
+    # dense rows take their candidates from per-pair bitmaps (presence matrix of the batch's references): a batch is
+    # bounded by the bitmaps of its pairs -- 512 rows of 9,999 pairs -- and every batch is one bitmap-fed launch
+    assert lay["tag_words"] == 1 and lay["n_free"] == 1
+    assert lay["bitmap_launches"] == lay["batches_last_run"] == 20 and lay["block_launches"] == 0
     mat, lit, comp = flat[..., 0], flat[..., 1], flat[..., 2]
     assert flat.min() >= 0
     assert np.array_equal(comp == 0, (mat == 0) & (lit == 0))
