@@ -393,6 +393,17 @@ struct DevWave {
     // candidate in lost mode and runs a round only over the <= mqd+1 tracking steps after an event.  Replaces the
     // rounds of 64 speculative steps with one wave-wide verification per candidate (find_event_round), which stay
     // for the other index forms.  Host model: tests/model/queue_wave.h.
+    // inclusive prefix sum over the 64 lanes: row shifts inside the rows of 16, then the row broadcasts (gfx9 DPP)
+    static __device__ __forceinline__ int wave_incl_scan(int v)
+    {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);      // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);      // row_shr:4
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);      // row_shr:8
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+        return v;
+    }
     __device__ __forceinline__ void lds_order() const
     {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -410,22 +421,30 @@ struct DevWave {
         // Four chunks of 64 positions per turn: their k-mer words are requested together, then their tag words (two
         // memory round trips per 256 positions instead of eight), then the candidates are compacted chunk by chunk.
         // A turn may look beyond iend or find more than the queue takes: the surplus is masked / detected again.
-        for (int turn = 0; JOIN && turn < AQ_MAXCHUNKS / 4 && scan_pos < iend && ncand < AQ_CAP; ++turn) {
-            // join form: the candidates of 64 positions are one (unaligned) word of the pair's bitmap
+        if (JOIN && scan_pos < iend) {
+            // Bitmap form: ONE 64-bit word of the pair's candidate bitmap per lane = 4,096 query positions a refill, all
+            // of it lane-parallel (the wave-uniform chunk loop this replaces cost ~20 scalar instructions per 64
+            // positions, and the kernel is bound by the scalar unit): popcount, a prefix sum over the lanes (DPP), then
+            // every lane peels its own candidates into the compaction buffer, lowest bit first -- as many turns as the
+            // fullest word has candidates (~5 for chance anchors).  Ranks 0 .. AQ_CAP go out (the last one only to tell
+            // the next refill where to start).
             const u32 w0 = (u32)scan_pos >> 6;
-            const int sh = scan_pos & 63;
-            const unsigned long long wd = cand_bits[w0 + (u32)imin(lane, 4)];        // lanes 0..4: the five words of this turn
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (scan_pos >= iend || ncand >= AQ_CAP) break;               // wave-uniform
-                const u64 bal = ((bcast64(wd, c) >> sh) | ((bcast64(wd, c + 1) << 1) << (63 - sh))) & lowmask(iend - scan_pos);
-                if (bal) {
-                    const int at = ncand + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                    if ((bal >> lane) & 1ULL) cq[at] = (u32)(scan_pos + lane);
-                    ncand += popc64(bal);
-                }
-                scan_pos = imin(scan_pos + 64, iend);
+            const int p_lo = (int)((w0 + (u32)lane) << 6);                  // first position of this lane's word
+            unsigned long long x = cand_bits[p_lo < iend ? w0 + (u32)lane : w0];
+            x &= ~lowmask(scan_pos - p_lo) & lowmask(iend - p_lo);          // positions in [scan_pos, iend)
+            const int cnt = popc64(x);
+            const int incl = wave_incl_scan(cnt);
+            int at = incl - cnt;
+            ncand = __builtin_amdgcn_readlane(incl, 63);
+            while (wballot((x != 0) & (at <= AQ_CAP)) != 0) {
+                const bool has = (x != 0) & (at <= AQ_CAP);
+                const u32 lo = (u32)x, hi = (u32)(x >> 32);
+                const int b = lo ? (int)__builtin_ctz(lo) : 32 + (int)__builtin_ctz(hi | 0x80000000u);
+                cq[has ? at : AQ_LDS_CAND - 1] = (u32)(p_lo + b);
+                x &= x - 1;
+                at += 1;
             }
+            scan_pos = imin((int)((w0 + 64u) << 6), iend);                  // (more than AQ_CAP candidates: corrected below)
         }
         for (int turn = 0; !JOIN && turn < AQ_MAXCHUNKS / 4 && scan_pos < iend && ncand < AQ_CAP; ++turn) {
             u32 hq[4], w[4];

@@ -572,6 +572,49 @@ def test_join_form_of_candidate_detection(monkeypatch):
             e += 1
 
 
+def test_presence_matrix_candidates(monkeypatch):
+    """Dense rows: the candidates of every pair come from per-pair bitmaps made ahead from the presence matrix of the
+    batch's references (k_pm_build, k_pm_cand) and the pair kernel reads them 64 positions per lane: whole matrices
+    against the oracle -- N-free and with N (poly-N stretches, an all-N genome), default and other parameters (mal 9
+    and 12: 18 and 24 key bits), genomes of very different lengths (tiles of 1,024 positions: queries of 1 to 20 tiles),
+    more rows than one group of 512 references and more than one batch (LZANI_PM_MAX_BYTES bounds the bitmaps)."""
+    _, seqs = SG.make_set(150, 31, lmin=17000, lmax=20000, fam=10)      # (tag words need >= 2^15 buckets)
+    withn = [s.copy() for s in seqs]
+    for k in range(0, 150, 7):
+        withn[k][300:300 + 5 + k % 40] = 5
+    withn.append(np.full(700, 5, dtype=np.uint8))
+    ragged = [s[: 900 + (k * 811) % len(s)] for k, s in enumerate(seqs[:60])]
+    _, longer = SG.make_set(40, 12, lmin=34000, lmax=36000, fam=8)      # (mal 12: 24 key bits, 2^17 buckets, 7 tag bits)
+    for name, data, prms in (("N-free", seqs, (None, dict(reg=30, aw=20), dict(mal=9, msl=6))),
+                             ("with N", withn, (None,)), ("ragged", ragged, (None,)), ("mal 12", longer, (dict(mal=12),))):
+        for prm in prms:
+            eng = L.Engine(prm)
+            eng.set_genomes(data)
+            got = eng.all2all()
+            lay = eng.layout()
+            eng.close()
+            assert lay["bitmap_launches"] == 1 and lay["block_launches"] == 0 and lay["tag_words"] == 1, (name, prm, lay)
+            want = O.oracle_all2all(data, prm, threads=16)
+            bad = np.argwhere((got != want).any(axis=2))
+            assert len(bad) == 0, (name, prm, bad[:3].tolist())
+    # several groups of 512 references in one batch, then several batches (the bitmaps of 64 rows at a time)
+    _, small = SG.make_set(1100, 77, lmin=1500, lmax=2500, fam=10)
+    prm = dict(mal=9, msl=6)
+    want = O.oracle_all2all(small, prm, threads=16)
+    eng = L.Engine(prm)
+    eng.set_genomes(small)
+    got = eng.all2all()
+    lay = eng.layout()
+    assert lay["bitmap_launches"] == 1 and lay["batches_last_run"] == 1, lay
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("LZANI_PM_MAX_BYTES", str(64 * 1099 * 3 * 128))     # 64 rows of 1,099 bitmaps of 3 tiles
+    got = eng.all2all()
+    lay = eng.layout()
+    eng.close()
+    assert lay["bitmap_launches"] == lay["batches_last_run"] == 18, lay
+    assert np.array_equal(got, want)
+
+
 def test_block_kernel_with_lds_filter(monkeypatch):
     """Rows of >= 128 pairs run by blocks of 16 waves that keep the reference's presence filter in LDS (k_pairs_blk,
     with the null chain where the parameters are the defaults): whole matrices against the oracle -- N-free and with N,
@@ -582,6 +625,9 @@ def test_block_kernel_with_lds_filter(monkeypatch):
     for k in range(0, 150, 7):
         withn[k][300:300 + 5 + k % 40] = 5
     want = {}
+    # (dense rows take their candidates from the presence matrix by default -- test_presence_matrix_candidates; the
+    # block kernel serves them where that form does not apply: mal > 12, fewer than 32 rows, LZANI_PM=0)
+    monkeypatch.setenv("LZANI_PM", "0")
     for name, data, prms in (("N-free", seqs, (None, dict(reg=30, aw=20))), ("with N", withn, (None,))):
         for prm in prms:
             eng = L.Engine(prm)
@@ -589,7 +635,7 @@ def test_block_kernel_with_lds_filter(monkeypatch):
             got = eng.all2all()
             lay = eng.layout()
             eng.close()
-            assert lay["block_launches"] == 1 and lay["tag_words"] == 1, (name, prm)
+            assert lay["block_launches"] == 1 and lay["bitmap_launches"] == 0 and lay["tag_words"] == 1, (name, prm)
             want[(name, str(prm))] = O.oracle_all2all(data, prm, threads=16)
             bad = np.argwhere((got != want[(name, str(prm))]).any(axis=2))
             assert len(bad) == 0, (name, prm, bad[:3].tolist())
