@@ -512,7 +512,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             if (fit < 8) pm = false;                          // (a genome set this large: the probe form, batch by batch)
             else {
                 bs = (u32)std::min<u64>(bs, fit);
-                if (bs > PM_GROUP) bs -= bs % PM_GROUP;       // whole groups
+                if (bs < n_rows && bs > PM_GROUP) bs -= bs % PM_GROUP;       // several batches: whole groups
                 const size_t need = (size_t)std::min(bs, n_rows) * per_row;
                 if (c->pm_cbits_bytes < need) {
                     hipFree(c->d_pm_cbits); c->d_pm_cbits = nullptr; c->pm_cbits_bytes = 0;
