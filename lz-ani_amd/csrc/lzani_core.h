@@ -751,6 +751,7 @@ struct PairMachine {
                     if (last_cl) { g.cl = last_cl; g.clit = last_clit; g.nl = 0; }  // discard + the match (+ forward extension) of the last event
                 }
             }
+            w.stamp(4);
             const bool hit = in_hand == 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);
 #if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
             w.st[6] += hit && in_hand != 2;

@@ -748,7 +748,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         unsigned long long tot = 0;
         for (int k = 0; k < 8; ++k) tot += acc[k];
         fprintf(stderr, "[lzani stamps] pairs=%llu total_cycles/pair=%.0f shares:", (unsigned long long)n_pairs, (double)tot / (double)n_pairs);
-        const char* nm[8] = {"setup", "anchors", "seeds", "event", "-", "ext_fwd", "tail", "post_ballot"};
+        const char* nm[8] = {"setup", "null_chain", "refill", "event", "find_event", "ext_fwd", "tail", "-"};
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)acc[k] / (double)tot);
         fprintf(stderr, "\n");
         unsigned long long z[8] = {0};

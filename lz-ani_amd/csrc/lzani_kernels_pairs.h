@@ -414,6 +414,10 @@ struct DevWave {
 #ifdef LZANI_CHAIN_STATS
         st[7] += 1;
 #endif
+#ifdef LZANI_STAMPS
+        const int stamp_sv = cur;
+        stamp(2);
+#endif
         u32* const cq = bitmap;                                 // (all zero again when refill returns)
         const int tb = I.kb - I.dirbits;
         scan_pos = imax(scan_pos, from);
@@ -556,6 +560,52 @@ struct DevWave {
             a_pos = lane < q_cnt ? mp : (int)AQ_NONE;
             a_len = ml; a_ref = (u32)mr; a_ext = (u32)mx;
         }
+        if constexpr (CHAIN) chain_classes();
+#ifdef LZANI_STAMPS
+        stamp(stamp_sv);
+#endif
+    }
+    // the length word of queue entry k (wave-uniform k): with the null chain its low byte, the rest is chain_classes'
+    __device__ __forceinline__ int len_at(int k) const
+    {
+        const int v = __builtin_amdgcn_readlane(a_len, k);
+        return CHAIN ? (int)(signed char)(v & 0xFF) : v;
+    }
+    // What the null chain (below) may take for granted about candidate j, worked out for the whole batch at once by the
+    // lanes -- the scalar unit is what bounds this kernel, and this is ~25 of its instructions per event: IF j has been
+    // committed as a null event by its record (backward extension from the record, i.e. the machine could look back
+    // at least aw symbols), THEN bits 8..14 = the next candidate the scan meets (the first one at or behind the end of
+    // j's match and forward extension) and bit 15 (GO) = that candidate is the next null event, for certain: j's
+    // tracking round is complete (query and reference ends far enough), the region j opened is short (dropped), the
+    // successor is plain, distant from j, its record holds both extensions and it sits at least aw symbols into both
+    // texts.  (Then its reach is >= aw as well: what it may look back at grows from event to event while regions are
+    // dropped.)  Only "no seed candidate in j's tracking round" is left to the loop.  The parameters are the defaults.
+    __device__ __forceinline__ void chain_classes()
+    {
+        enum { MQD = 40, MRD = 40, MSL = 7, REG = 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };
+        const int ilim = imin(scan_pos, iend) - NT, rlim = R.len - MSL + 1 - WIN;
+        const int len = a_len;
+        const bool plain = len > 0;
+        const u32 rec = a_ext;
+        const int pos = (int)(a_ref & AQ_POS);
+        const int t2 = len + (int)((rec >> 24) & 31u);
+        const int end = a_pos + t2, rend = pos + t2;
+        const bool both = (rec & (EXT_REC_FWDK | EXT_REC_BRKB)) == (u32)(EXT_REC_FWDK | EXT_REC_BRKB);
+        const bool cap = plain & both & (imin(a_pos, pos) >= AW);                      // as a successor
+        const bool pred = plain & both & (end <= ilim) & (rend <= rlim) & (t2 + (int)(rec & 15u) < REG);   // as a predecessor
+        const int mine = (int)((u32)pos | (cap ? 0x80000000u : 0u));
+        int succ = 64, s_pos = 0, s_u = 0;
+#pragma unroll
+        for (int d = 3; d >= 1; --d) {               // (positions ascend: the smallest d that qualifies is written last)
+            const int l = lane + d;
+            const int p = __builtin_amdgcn_ds_bpermute(4 * l, a_pos), u = __builtin_amdgcn_ds_bpermute(4 * l, mine);
+            const bool ok = (l < 64) & (p >= end);
+            succ = ok ? l : succ; s_pos = ok ? p : s_pos; s_u = ok ? u : s_u;
+        }
+        const int gap = s_pos - end;
+        const bool distant = (gap > MQD) | (iabs((s_u & 0x7FFFFFFF) - (rend + gap)) > MRD);
+        const bool go = pred & (succ < q_cnt) & (s_u < 0) & distant;
+        a_len = (len & 0xFF) | (succ << 8) | (go ? 0x8000 : 0);
     }
     __device__ __forceinline__ bool ext_record(u32& x) const
     {
@@ -586,7 +636,7 @@ struct DevWave {
             return;
         }
         ap = (int)(ref & AQ_POS);
-        al = __builtin_amdgcn_readlane(a_len, k);
+        al = len_at(k);
         al = al < 0 ? -1 - al : al;
         if (__builtin_expect((ref & AQ_LONG) != 0, 0)) al = wave_equal_len(ap, qp, AQ_LANE_CAP);
         // a candidate is a k-mer hit in the genome's REFERENCE text; as a query the text ends at D, and with
@@ -633,7 +683,6 @@ struct DevWave {
         qk = lane < nt ? qk : KM_INVALID;
         rk0 = lane < W ? rk0 : KM_INVALID;
         rk1 = lane + 64 < W ? rk1 : KM_INVALID;
-        stamp(2);
         return wballot(seed_prefilter(rk0, rk1, qk));
     }
 
@@ -672,6 +721,14 @@ struct DevWave {
         const u32* const rks = uniform_ptr(rkS);
         int code, ap, rec, t0, t1, t2, kb, kc, qh = q_head;
         u64 m, seed;
+#ifdef LZANI_STAMPS                         // (diagnostic build: the stamp bookkeeping makes the compiler lose sight of the uniformity)
+        i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end); qh = __builtin_amdgcn_readfirstlane(qh);
+        prev_rs = __builtin_amdgcn_readfirstlane(prev_rs); prev_re = __builtin_amdgcn_readfirstlane(prev_re);
+        pre_lit = __builtin_amdgcn_readfirstlane(pre_lit);
+        const int qc_u = __builtin_amdgcn_readfirstlane(q_cnt), ilim_u = __builtin_amdgcn_readfirstlane(ilim), rlim_u = __builtin_amdgcn_readfirstlane(rlim);
+#else
+        const int qc_u = q_cnt, ilim_u = ilim, rlim_u = rlim;
+#endif
         u32 rk0, rk1, qk, a0, a1, aq, t, bq;
 #ifdef LZANI_CHAIN_STATS
         int ncnt = 0;
@@ -681,6 +738,74 @@ struct DevWave {
 #define LZ_NC_COUNT
 #define LZ_NC_COUNT_OPERAND
 #endif
+        // the three loads of a tracking round (msl-mers of the 41 steps and of the 80 window positions) and its lane masks
+#define LZ_NC_LOADS \
+            "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t" \
+            "v_add_lshl_u32 %[a1], %[lane], %[rend], 2\n\t" \
+            "v_or_b32_e32 %[aq], 64, %[lane]\n\t" \
+            "v_min_u32_e32 %[aq], %[W1], %[aq]\n\t" \
+            "v_add_lshl_u32 %[aq], %[aq], %[rend], 2\n\t" \
+            "global_load_dword %[qk], %[a0], %[qks]\n\t" \
+            "global_load_dword %[rk0], %[a1], %[rks]\n\t" \
+            "global_load_dword %[rk1], %[aq], %[rks]\n\t" \
+            "v_cmp_gt_u32_e32 vcc, %[NT], %[lane]\n\t" \
+            "v_cmp_gt_u32_e64 %[m], %[NR1], %[lane]\n\t"
+        // the round itself (track_round + seed_prefilter): window k-mers into the LDS bitmap, every step tests its own, the
+        // bits are cleared again; leaves the steps with a seed candidate in m & vcc
+#define LZ_NC_ROUND \
+            "s_waitcnt vmcnt(0)\n\t" \
+            "v_cndmask_b32_e32 %[qk], -1, %[qk], vcc\n\t" \
+            "v_cndmask_b32_e64 %[rk1], -1, %[rk1], %[m]\n\t" \
+            "v_cmp_eq_u32_e32 vcc, -1, %[rk0]\n\t" \
+            "v_lshrrev_b32_e32 %[a0], 5, %[rk0]\n\t" \
+            "v_lshlrev_b32_e64 %[t], %[rk0], 1\n\t" \
+            "v_cndmask_b32_e32 %[a0], %[a0], %[scrw], vcc\n\t" \
+            "v_cndmask_b32_e64 %[t], %[t], 0, vcc\n\t" \
+            "v_cmp_eq_u32_e64 %[m], -1, %[rk1]\n\t" \
+            "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t" \
+            "ds_or_b32 %[a0], %[t]\n\t" \
+            "v_lshrrev_b32_e32 %[a1], 5, %[rk1]\n\t" \
+            "v_lshlrev_b32_e64 %[bq], %[rk1], 1\n\t" \
+            "v_cndmask_b32_e64 %[a1], %[a1], %[scrw], %[m]\n\t" \
+            "v_cndmask_b32_e64 %[bq], %[bq], 0, %[m]\n\t" \
+            "v_cmp_ne_u32_e32 vcc, -1, %[qk]\n\t" \
+            "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t" \
+            "ds_or_b32 %[a1], %[bq]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], 5, %[qk]\n\t" \
+            "v_lshlrev_b32_e64 %[t], %[qk], 1\n\t" \
+            "v_cndmask_b32_e32 %[aq], %[scrw], %[aq], vcc\n\t" \
+            "v_lshl_add_u32 %[aq], %[aq], 2, %[ldsb]\n\t" \
+            "ds_read_b32 %[aq], %[aq]\n\t" \
+            "ds_write_b32 %[a0], %[zero]\n\t" \
+            "ds_write_b32 %[a1], %[zero]\n\t" \
+            "s_waitcnt lgkmcnt(2)\n\t" \
+            "v_and_b32_e32 %[aq], %[aq], %[t]\n\t" \
+            "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t"
+        // a seed candidate matters only up to the step of the queued candidate itself (gap steps ahead): m = the steps
+        // with a seed candidate among them (scc = any); seed keeps them all for find_event
+#define LZ_NC_SEEDS \
+            "s_and_b64 %[seed], %[m], vcc\n\t" \
+            "s_add_i32 %[t0], %[gap], 1\n\t" \
+            "s_min_u32 %[t0], %[t0], 63\n\t" \
+            "s_bfm_b64 %[m], %[t0], 0\n\t" \
+            "s_and_b64 %[m], %[m], %[seed]\n\t"
+        // the null event: the machine's state after it (see PairMachine::run)
+#define LZ_NC_COMMIT \
+            "s_sub_i32 %[plit], %[t1], %[kb]\n\t"           /* what is left of the literals before the backward extension */ \
+            "s_sub_i32 %[prs], %[ap], %[kb]\n\t"            /* the region starts with it */ \
+            "s_bfe_u32 %[t0], %[rec], 0x50018\n\t"          /* e: the forward extension's length (bits 24..28) */ \
+            "s_bfe_u32 %[lastlit], %[rec], 0x40014\n\t"     /* its mismatches (bits 20..23) */ \
+            "s_add_i32 %[t2], %[blen], %[t0]\n\t" \
+            "s_sub_i32 %[lastb], %[t2], %[lastlit]\n\t"     /* the region's matches: the anchor, the extensions' */ \
+            "s_add_i32 %[lastb], %[lastb], %[kc]\n\t" \
+            "s_add_i32 %[lastlit], %[lastlit], %[kb]\n\t"   /* and its literals: the extensions' mismatches */ \
+            "s_sub_i32 %[lastlit], %[lastlit], %[kc]\n\t" \
+            "s_add_i32 %[i], %[ap], %[t2]\n\t" \
+            "s_add_i32 %[rend], %[bpos], %[t2]\n\t" \
+            "s_mov_b32 %[pre], %[i]\n\t" \
+            "s_add_i32 %[qh], %[qh], 1\n\t" \
+            LZ_NC_COUNT
+        int gap, cls, fok;
         asm volatile(
             "s_mov_b32 %[code], 0\n\t"
             "s_mov_b32 %[lastb], 0\n\t"
@@ -705,17 +830,7 @@ struct DevWave {
             "s_cbranch_scc1 Lnc_end_%=\n\t"
             "s_cmp_gt_i32 %[rend], %[rlim]\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"
-            // the tracking round (track_round + seed_prefilter): msl-mers of the 41 steps and of the 80 window positions
-            "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t"
-            "v_add_lshl_u32 %[a1], %[lane], %[rend], 2\n\t"
-            "v_or_b32_e32 %[aq], 64, %[lane]\n\t"
-            "v_min_u32_e32 %[aq], %[W1], %[aq]\n\t"
-            "v_add_lshl_u32 %[aq], %[aq], %[rend], 2\n\t"
-            "global_load_dword %[qk], %[a0], %[qks]\n\t"
-            "global_load_dword %[rk0], %[a1], %[rks]\n\t"
-            "global_load_dword %[rk1], %[aq], %[rks]\n\t"
-            "v_cmp_gt_u32_e32 vcc, %[NT], %[lane]\n\t"
-            "v_cmp_gt_u32_e64 %[m], %[NR1], %[lane]\n\t"
+            LZ_NC_LOADS
             // While the loads fly: the next queued candidate and, should the round find no seed candidate, whether it is
             // a null event (t2 = 1): plain, distant, the open region short (dropped), both extensions empty by the record
             "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
@@ -723,10 +838,11 @@ struct DevWave {
             "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
             "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
             "s_mov_b32 %[t2], 0\n\t"
+            "s_sext_i32_i8 %[blen], %[blen]\n\t"            // (the rest of the word is chain_classes')
+            "s_sub_i32 %[gap], %[ap], %[i]\n\t"
             "s_cmp_lt_i32 %[blen], 1\n\t"
             "s_cbranch_scc1 Lnc_chk_%=\n\t"
-            "s_sub_i32 %[t0], %[ap], %[i]\n\t"
-            "s_cmp_le_i32 %[t0], %[MQD]\n\t"
+            "s_cmp_le_i32 %[gap], %[MQD]\n\t"
             "s_cbranch_scc1 Lnc_close_%=\n"
             "Lnc_distant_%=:\n\t"
             "s_cmp_lt_i32 %[prs], 0\n\t"
@@ -742,6 +858,7 @@ struct DevWave {
             "s_min_i32 %[t0], %[t0], %[bpos]\n\t"           // reach
             "s_mov_b32 %[kb], 0\n\t"                          // the backward extension: empty, unless the record holds it
             "s_mov_b32 %[kc], 0\n\t"
+            "s_mov_b32 %[fok], 0\n\t"
             "s_cmp_lt_i32 %[t0], 1\n\t"
             "s_cbranch_scc1 Lnc_ok_%=\n\t"
             "s_bitcmp1_b32 %[rec], 30\n\t"
@@ -757,65 +874,55 @@ struct DevWave {
             "s_cmp_lt_i32 %[t0], %[AW]\n\t"                 // (given the full first window)
             "s_cbranch_scc1 Lnc_chk_%=\n\t"
             "s_and_b32 %[kb], %[rec], 15\n\t"
-            "s_bfe_u32 %[kc], %[rec], 0x40004\n"
+            "s_bfe_u32 %[kc], %[rec], 0x40004\n\t"
+            "s_mov_b32 %[fok], 1\n"                          // committed by its record: what chain_classes assumes
             "Lnc_ok_%=:\n\t"
             "s_mov_b32 %[t2], 1\n"
             "Lnc_chk_%=:\n\t"
-            "s_waitcnt vmcnt(0)\n\t"
-            "v_cndmask_b32_e32 %[qk], -1, %[qk], vcc\n\t"
-            "v_cndmask_b32_e64 %[rk1], -1, %[rk1], %[m]\n\t"
-            "v_cmp_eq_u32_e32 vcc, -1, %[rk0]\n\t"
-            "v_lshrrev_b32_e32 %[a0], 5, %[rk0]\n\t"
-            "v_lshlrev_b32_e64 %[t], %[rk0], 1\n\t"
-            "v_cndmask_b32_e32 %[a0], %[a0], %[scrw], vcc\n\t"
-            "v_cndmask_b32_e64 %[t], %[t], 0, vcc\n\t"
-            "v_cmp_eq_u32_e64 %[m], -1, %[rk1]\n\t"
-            "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t"
-            "ds_or_b32 %[a0], %[t]\n\t"
-            "v_lshrrev_b32_e32 %[a1], 5, %[rk1]\n\t"
-            "v_lshlrev_b32_e64 %[bq], %[rk1], 1\n\t"
-            "v_cndmask_b32_e64 %[a1], %[a1], %[scrw], %[m]\n\t"
-            "v_cndmask_b32_e64 %[bq], %[bq], 0, %[m]\n\t"
-            "v_cmp_ne_u32_e32 vcc, -1, %[qk]\n\t"
-            "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t"
-            "ds_or_b32 %[a1], %[bq]\n\t"
-            "v_lshrrev_b32_e32 %[aq], 5, %[qk]\n\t"
-            "v_lshlrev_b32_e64 %[t], %[qk], 1\n\t"
-            "v_cndmask_b32_e32 %[aq], %[scrw], %[aq], vcc\n\t"
-            "v_lshl_add_u32 %[aq], %[aq], 2, %[ldsb]\n\t"
-            "ds_read_b32 %[aq], %[aq]\n\t"
-            "ds_write_b32 %[a0], %[zero]\n\t"
-            "ds_write_b32 %[a1], %[zero]\n\t"
-            "s_waitcnt lgkmcnt(2)\n\t"
-            "v_and_b32_e32 %[aq], %[aq], %[t]\n\t"
-            "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t"
+            LZ_NC_ROUND
             "s_mov_b32 %[code], 1\n\t"
-            "s_and_b64 %[seed], %[m], vcc\n\t"
+            LZ_NC_SEEDS
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // a seed candidate: the round is done, the rest is find_event's
             "s_cmp_lt_i32 %[blen], 1\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the candidate is not plain: likewise
             "s_mov_b32 %[code], 2\n\t"
             "s_cmp_eq_u32 %[t2], 0\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the event is found but is not a null event
-            // the null event
-            "s_sub_i32 %[plit], %[t1], %[kb]\n\t"           // what is left of the literals before the backward extension
-            "s_sub_i32 %[prs], %[ap], %[kb]\n\t"            // the region starts with it
-            "s_bfe_u32 %[t0], %[rec], 0x50018\n\t"          // e: the forward extension's length (bits 24..28)
-            "s_bfe_u32 %[lastlit], %[rec], 0x40014\n\t"     // its mismatches (bits 20..23)
-            "s_add_i32 %[t2], %[blen], %[t0]\n\t"
-            "s_sub_i32 %[lastb], %[t2], %[lastlit]\n\t"     // the region's matches: the anchor, the extensions'
-            "s_add_i32 %[lastb], %[lastb], %[kc]\n\t"
-            "s_add_i32 %[lastlit], %[lastlit], %[kb]\n\t"   // and its literals: the extensions' mismatches
-            "s_sub_i32 %[lastlit], %[lastlit], %[kc]\n\t"
-            "s_add_i32 %[i], %[ap], %[t2]\n\t"
-            "s_add_i32 %[rend], %[bpos], %[t2]\n\t"
-            "s_mov_b32 %[pre], %[i]\n\t"
-            "s_add_i32 %[qh], %[qh], 1\n\t"
+            LZ_NC_COMMIT
             "s_mov_b32 %[code], 0\n\t"
-            LZ_NC_COUNT
-            "s_branch Lnc_top_%=\n"
+            "s_cmp_eq_u32 %[fok], 0\n\t"
+            "s_cbranch_scc1 Lnc_top_%=\n"
+            // The fast turn: the candidate just committed (queue entry qh - 1) was a null event by its record, so
+            // chain_classes' word says which entry the scan meets next and whether that is the next null event for
+            // certain (GO) -- then only this entry's tracking round is left to do
+            "Lnc_fast_%=:\n\t"
+            "s_sub_i32 %[t2], %[qh], 1\n\t"
+            "v_readlane_b32 %[cls], %[alen], %[t2]\n\t"
+            "s_bitcmp0_b32 %[cls], 15\n\t"
+            "s_cbranch_scc1 Lnc_top_%=\n\t"
+            "s_bfe_u32 %[qh], %[cls], 0x70008\n\t"          // the successor (the entries between are passed)
+            LZ_NC_LOADS
+            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
+            "v_readlane_b32 %[ap], %[apos], %[qh]\n\t"
+            "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
+            "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
+            "s_sext_i32_i8 %[blen], %[blen]\n\t"
+            "s_sub_i32 %[gap], %[ap], %[i]\n\t"
+            "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
+            "s_add_i32 %[t1], %[t1], %[plit]\n\t"           // avail
+            "s_and_b32 %[kb], %[rec], 15\n\t"
+            "s_bfe_u32 %[kc], %[rec], 0x40004\n\t"
+            LZ_NC_ROUND
+            "s_nop 0\n\t"
+            LZ_NC_SEEDS
+            "s_cbranch_scc1 Lnc_fseed_%=\n\t"
+            LZ_NC_COMMIT
+            "s_branch Lnc_fast_%=\n"
+            "Lnc_fseed_%=:\n\t"                             // a seed candidate: as above (the queue head is the successor)
+            "s_mov_b32 %[code], 1\n\t"
+            "s_branch Lnc_end_%=\n"
             "Lnc_close_%=:\n\t"                             // a tracking step: close to the predicted position = not ours
-            "s_add_i32 %[t1], %[rend], %[t0]\n\t"
+            "s_add_i32 %[t1], %[rend], %[gap]\n\t"
             "s_sub_i32 %[t1], %[bpos], %[t1]\n\t"
             "s_abs_i32 %[t1], %[t1]\n\t"
             "s_cmp_le_i32 %[t1], %[MRD]\n\t"
@@ -827,12 +934,17 @@ struct DevWave {
             : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit),
               [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec),
               [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [m] "=&s"(m), [seed] "=&s"(seed),
+              [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok),
               [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq)
-            : [qc] "s"(q_cnt), [ilim] "s"(ilim), [rlim] "s"(rlim), [qks] "s"(qks), [rks] "s"(rks),
+            : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks),
               [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), [scrw] "v"(scrw),
               [ldsb] "v"(ldsb), [zero] "v"(zero),
               [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [W1] "n"(WIN - 1), [NR1] "n"(WIN - 64)
             : "vcc", "scc", "memory");
+#undef LZ_NC_LOADS
+#undef LZ_NC_ROUND
+#undef LZ_NC_SEEDS
+#undef LZ_NC_COMMIT
         q_head = qh;
         pre_round = code == 1;
         pre_seed = seed; pre_rk0 = rk0; pre_rk1 = rk1; pre_qk = qk;
@@ -865,9 +977,8 @@ struct DevWave {
             // arbitration unopposed unless it sits at reference position 0 (quirk Q1): a PLAIN candidate is the event
             // whether it is still a tracking step or already a lost one.
             if (trk) { seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk); round_done = true; }
-            stamp(7);
             if (__builtin_expect((seedmask == 0) & (lit + nt > P.mqd) & (q_head < q_cnt), 1)) {
-                const int plen = __builtin_amdgcn_readlane(a_len, q_head);
+                const int plen = len_at(q_head);
                 if (__builtin_expect(plen > 0, 1)) {
                     adv = __builtin_amdgcn_readlane(a_pos, q_head) - i;
                     bpos = (int)((u32)__builtin_amdgcn_readlane((int)a_ref, q_head)); blen = plen;
@@ -977,7 +1088,7 @@ struct DevWave {
                 continue;
             }
             const int qp = __builtin_amdgcn_readlane(a_pos, q_head);
-            const int plen = __builtin_amdgcn_readlane(a_len, q_head);
+            const int plen = len_at(q_head);
             if (__builtin_expect(plen > 0, 1)) {                     // a plain candidate: the event, whatever kind of step it is
                 adv = qp - i; bpos = (int)((u32)__builtin_amdgcn_readlane((int)a_ref, q_head)); blen = plen;
                 last_src = q_head++;
@@ -1133,7 +1244,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
     const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
 #ifdef LZANI_STAMPS
-    constexpr bool CHAIN = false;                   // (the diagnostic build times the compiler's own sections)
+    constexpr bool CHAIN = FAST && BK && DEFP && !ALN && !LFLT;     // (diagnostic build: the block kernel's stamps do not stay scalar around the hand-written loop)
 #else
     constexpr bool CHAIN = FAST && BK && DEFP && !ALN;
 #endif
@@ -1184,8 +1295,11 @@ __device__ __forceinline__ u32 row_of_ticket(const u64* __restrict__ qcum, u32 r
 // defaults (params.h:34-48), folded into the code as constants.
 // ALN = also emit the regions of every pair (--out-alignment).
 // JOIN = candidates by a join with sorted k-mer lists (long genomes; needs FAST and BK).
+#ifndef LZANI_WAVES_PER_SIMD
+#define LZANI_WAVES_PER_SIMD 8                 // (occupancy experiments: the register budget of the pair kernel)
+#endif
 template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false, int CAND = 0>
-__global__ void __launch_bounds__(256, 8) k_pairs(PairArgs a)
+__global__ void __launch_bounds__(256, LZANI_WAVES_PER_SIMD) k_pairs(PairArgs a)
 {
     const int lane = threadIdx.x & 63;
     __shared__ u32 s_seed[4][SEED_LDS_WORDS];
