@@ -12,9 +12,9 @@ scaling: the total work is fixed, the rows are shared out).
 A step = one SLAB of the all2all: 500 consecutive reference rows (in the reference's length-descending
 order) against all other genomes = 4,999,500 directed pairs, i.e. one pass of the hot path over one batch:
 per-reference index build + pair kernel on every rank's share of the slab (rows dealt cyclically over the
-ranks by the C-ABI's lzani_partition_rows) + one RCCL all-gather of the per-pair int32[3] records (N > 1,
-lzani_comm_allgather inside the engine library -- torch.distributed only carries the rendezvous, the
-unique id and the barriers).  `--steps 20` is exactly one pass over the 10k x 10k matrix; the slabs wrap
+ranks by the C-ABI's lzani_partition_rows) + one RCCL all-gather of the per-pair int32[3] records (N > 1:
+torch.distributed's nccl backend by default, `--collective lzani` = lzani_comm_allgather inside the engine
+library, which no pool has yet let run on more than one GPU).  `--steps 20` is exactly one pass over the 10k x 10k matrix; the slabs wrap
 around.  Genomes are resident in HBM before the timed region; results stay in HBM.
 
 `roofline` is for the pair kernel (k_pairs): algorithmic bytes B_pair summed over the pairs
@@ -123,8 +123,9 @@ def main():
     ap.add_argument("--lmin", type=int, default=36000, help="ancestor length range of the synthetic set")
     ap.add_argument("--lmax", type=int, default=44000)
     ap.add_argument("--params", default="", help="LZ parameter overrides, e.g. mal=15,msl=9,reg=60 (BASELINE configs[3])")
-    ap.add_argument("--collective", default="lzani", choices=("lzani", "torch", "gloo"),
-                    help="lzani: RCCL all-gather inside the engine library (lzani_comm_allgather); torch: torch.distributed nccl; "
+    ap.add_argument("--collective", default="torch", choices=("lzani", "torch", "gloo"),
+                    help="torch: torch.distributed nccl (= RCCL) all-gather, the default until the library's own communicator has run on "
+                         "more than one GPU; lzani: RCCL all-gather inside the engine library (lzani_comm_allgather); "
                          "gloo: host-side all_gather -- only for rehearsing the N > 1 logic with several ranks on ONE GPU (--device 0), "
                          "where RCCL refuses to run")
     ap.add_argument("--device", type=int, default=-1, help="force the HIP device ordinal")
@@ -173,11 +174,13 @@ def main():
     gathered = torch.zeros(world * per_rank * 3, dtype=torch.int32, device="cuda") if world > 1 else None
     host_parts = [torch.zeros(per_rank * 3, dtype=torch.int32) for _ in range(world)] if args.collective == "gloo" else None
 
-    def step(s):
+    def step(s, acc=None):
         rows = SH.slab_rows(n, s, slab)
         mine = SH.rank_rows(rows, rank, world)
         ref_ids, row_off = L.dense_rows(n, mine)
-        eng.run_rows_device(ref_ids, row_off, None, shard.data_ptr())
+        t_a = time.perf_counter()
+        eng.run_rows_device(ref_ids, row_off, None, shard.data_ptr())      # (blocking: returns when the shard is complete)
+        t_b = time.perf_counter()
         if world > 1:
             if args.collective == "lzani":
                 eng.comm_allgather(shard.data_ptr(), gathered.data_ptr(), per_rank)
@@ -186,6 +189,14 @@ def main():
             else:
                 dist.all_gather(host_parts, shard.cpu())
                 gathered.copy_(torch.cat(host_parts))
+            if acc is not None:
+                torch.cuda.synchronize()                                    # (the gather on this rank, for the per-rank split below)
+        if acc is not None:
+            tm = eng.timing()
+            acc["compute_ms"] += (t_b - t_a) * 1e3
+            acc["gather_ms"] += (time.perf_counter() - t_b) * 1e3
+            acc["kernel_ms"] += tm["pairs_ms"]
+            acc["fixed_ms"] += tm["index_ms"] + tm["cand_ms"] + tm["kmers_ms"]   # not sharded by rows: k-mer words (first run only), index build, candidate stage
         return rows, mine
 
     def fence():
@@ -197,13 +208,15 @@ def main():
     for s in range(args.warmup):
         step(s)
     fence()
-    kernel_ms, index_ms, launches, abytes, total_pairs, my_pairs = 0.0, 0.0, 0, 0, 0, 0
+    kernel_ms, index_ms, cand_ms, launches, abytes, total_pairs, my_pairs = 0.0, 0.0, 0.0, 0, 0, 0, 0
+    split = {"compute_ms": 0.0, "kernel_ms": 0.0, "fixed_ms": 0.0, "gather_ms": 0.0}
     t0 = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
-        rows, mine = step(s)
+        rows, mine = step(s, split)
         tm = eng.timing()
         kernel_ms += tm["pairs_ms"]
         index_ms += tm["index_ms"]
+        cand_ms += tm["cand_ms"]
         launches += tm["pair_launches"]
         total_pairs += len(rows) * (n - 1)
         my_pairs += len(mine) * (n - 1)
@@ -215,6 +228,13 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.collective == "torch" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # per-rank split of the timed region (so that a scaling curve can be read the moment a node exists): host wall of the
+    # blocking compute call, device time of the pair kernel and of the stages that do not shrink with the rank's share
+    # of rows, host wall of the gather
+    splits = [split]
+    if world > 1:
+        splits = [None] * world
+        dist.all_gather_object(splits, split)
 
     out = None
     if rank == 0:
@@ -224,6 +244,7 @@ def main():
         avg_launch_ms = kernel_ms / launches
         achieved = abytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         lay = eng.layout()
+        kernel_name = "k_pairs_blk" if lay["block_launches"] else "k_pairs (candidate bitmaps)" if lay["bitmap_launches"] else "k_pairs"
         coll_name = {"lzani": "lzani_comm_allgather", "torch": "torch.distributed nccl",
                      "gloo": "REHEARSAL: gloo through host memory, ranks may share a GPU"}[args.collective]
         out = {
@@ -244,12 +265,17 @@ def main():
                        "params": params,
                        "index_form": {"dir_bits": lay["dir_bits"], "tag_words": lay["tag_words"], "bucket_table": lay["bucket_table"],
                                       "n_free": lay["n_free"], "slots": lay["slots"], "batches_per_step": lay["batches_last_run"],
-                                      "block_kernel_with_lds_filter": int(lay["block_launches"] > 0)}},
+                                      "block_kernel_with_lds_filter": int(lay["block_launches"] > 0),
+                                      "candidate_bitmaps_from_presence_matrix": int(lay["bitmap_launches"] > 0)}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.seed, slab, world),
-                         "kernel": "k_pairs_blk" if lay["block_launches"] else "k_pairs", "avg_launch_ms": avg_launch_ms, "launches": launches,
+                         "kernel": kernel_name, "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": abytes / launches,
-                         "index_build_ms_per_step": index_ms / args.steps},
+                         "index_build_ms_per_step": index_ms / args.steps, "candidate_stage_ms_per_step": cand_ms / args.steps},
+            "per_rank_ms_per_step": {k: {"by_rank": [round(sp[k] / args.steps, 3) for sp in splits],
+                                         "max": round(max(sp[k] for sp in splits) / args.steps, 3),
+                                         "mean": round(sum(sp[k] for sp in splits) / len(splits) / args.steps, 3)}
+                                     for k in ("compute_ms", "kernel_ms", "fixed_ms", "gather_ms")},
         }
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         n_check = int(max(4, min(64, 40e6 / max(1.0, float(lens.mean())))))       # oracle pairs checked: ~40 M symbols of CPU work
@@ -258,25 +284,40 @@ def main():
             sample_ids = np.arange(0, n, max(1, n // m), dtype=np.uint32)[:m]
             cb, cpu_res = cpu_baseline(seqs, params, sample_ids)
             out["cpu_baseline"] = cb
-            # free parity evidence: the same sampled pairs through the HIP path (untimed, filtered-row form)
-            q = np.array([[x for x in sample_ids if x != r] for r in sample_ids], dtype=np.uint32)
-            row_off = np.arange(len(sample_ids) + 1, dtype=np.uint64) * np.uint64(len(sample_ids) - 1)
-            got = eng.run_rows(sample_ids, row_off, q.reshape(-1)).reshape(len(sample_ids), len(sample_ids) - 1, 3)
-            want = cpu_res[~np.eye(len(sample_ids), dtype=bool)].reshape(len(sample_ids), len(sample_ids) - 1, 3)
-            out["cpu_baseline"]["parity_on_sample"] = "bit-exact" if np.array_equal(got, want) else "MISMATCH"
+            # free parity evidence: the same sampled pairs through the HIP path, untimed, as the dense all2all of the sample in a
+            # context of its own -- i.e. through the very kernel the timed region launches (dense rows)
+            eng2 = L.Engine(over or None, device=dev)
+            eng2.set_genomes([seqs[i] for i in sample_ids])
+            got = eng2.all2all()
+            lay2 = eng2.layout()
+            eng2.close()
+            k2 = "k_pairs_blk" if lay2["block_launches"] else "k_pairs (candidate bitmaps)" if lay2["bitmap_launches"] else "k_pairs"
+            out["cpu_baseline"]["parity_on_sample"] = "bit-exact" if np.array_equal(got, cpu_res) else "MISMATCH"
+            out["cpu_baseline"]["parity_on_sample_kernel"] = k2 + (" = the timed kernel" if k2 == kernel_name else " (NOT the timed kernel)")
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_check:
-            # pairs of the last timed slab, straight from the bench's own result buffer (dense-row form)
+            # pairs of the last timed slab, straight from the bench's own result buffer: >= 2,000 of them against the reference's
+            # CParser (oracle/_ref) where it is built, else n_check against the C restatement
             import oracle as O
             res = shard.cpu().numpy().reshape(rows_max, n - 1, 3)
-            ok = True
-            for k in range(n_check):
+            n_ref = 0 if O.lib_ref() is None else max(2000, n_check)
+            picks = []
+            for k in range(max(n_ref, n_check)):
                 i = (k * 7919) % len(mine)
                 r = int(mine[i])
                 qq = (r + 1 + (k * 104729) % (n - 1)) % n
-                ok &= tuple(int(x) for x in res[i, qq if qq < r else qq - 1]) == O.oracle_pair(seqs[r], seqs[qq], params)
+                picks.append((i, r, qq))
+            if n_ref:
+                rr = np.array([p[1] for p in picks], np.uint32)
+                want = O.ref_rows(seqs, rr, np.arange(len(picks) + 1, dtype=np.uint64), np.array([p[2] for p in picks], np.uint32), params,
+                                  threads=host_cores())
+                gotp = np.stack([res[i, qq if qq < r else qq - 1] for i, r, qq in picks])
+                ok = bool(np.array_equal(gotp, want))
+            else:
+                ok = all(tuple(int(x) for x in res[i, qq if qq < r else qq - 1]) == O.oracle_pair(seqs[r], seqs[qq], params) for i, r, qq in picks)
             out["parity_on_last_slab"] = "bit-exact" if ok else "MISMATCH"
+            out["parity_on_last_slab_pairs"] = len(picks)
         else:
             if world > 1:
                 # N > 1: pairs from every rank's rows of the last gathered slab against the oracle

@@ -181,11 +181,19 @@ int lzani_comm_gatherv(lzani_ctx *ctx, const void *d_send, void *d_recv, const u
 typedef struct lzani_group lzani_group;
 int lzani_group_create(const lzani_params *p, uint32_t n_devices, const int *device_ids, lzani_group **out);
 void lzani_group_destroy(lzani_group *grp);
-const char *lzani_group_last_error(const lzani_group *grp);
+const char *lzani_group_last_error(const lzani_group *grp);   /* grp == NULL: why the calling thread's last lzani_group_create failed */
 int lzani_group_set_genomes(lzani_group *grp, uint32_t n, const uint8_t *const *codes, const uint32_t *len);
 int lzani_group_run_rows(lzani_group *grp, uint32_t n_rows, const uint32_t *ref_ids, const uint64_t *row_off,
                          const uint32_t *query_ids, lzani_result *out);
 int lzani_group_get_timing(const lzani_group *grp, uint32_t device_index, lzani_timing *t, double *gather_ms);
+
+/* The shard bookkeeping of lzani_group_run_rows as a pure host function (no GPU): rows keep their order inside
+ * their shard, the shards follow each other in the gathered buffer (shard d from result shard_base[d] on,
+ * shard_base has n_parts + 1 entries); entry j of the scatter table -- j counts the rows shard by shard,
+ * row_of_entry[j] (may be NULL) names the row -- says where the row's results sit in the gathered buffer (src[j]),
+ * where they belong in the caller's CSR order (dst[j] = row_off[row]) and how many there are (cnt[j]). */
+int lzani_plan_gather(uint32_t n_rows, const uint64_t *row_off, const uint32_t *part_of_row, uint32_t n_parts,
+                      uint64_t *shard_base, uint64_t *src, uint64_t *dst, uint64_t *cnt, uint32_t *row_of_entry);
 
 /* Test hook: copies out the device-built packed reference text and anchor index of one genome
  * (any pointer may be NULL).  Sizes: nm = ((T+63)/64+2) u64, t2 = twice that, with

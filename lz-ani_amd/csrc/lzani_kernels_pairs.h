@@ -738,6 +738,11 @@ struct DevWave {
 #define LZ_NC_COUNT
 #define LZ_NC_COUNT_OPERAND
 #endif
+#if defined(LZANI_EXP) && LZANI_EXP == 4           // diagnostic build (wrong results): seed candidates ignored inside the chain
+#define LZ_NC_NOSEED "s_cmp_lg_u32 0, 0\n\t"
+#else
+#define LZ_NC_NOSEED
+#endif
         // the three loads of a tracking round (msl-mers of the 41 steps and of the 80 window positions) and its lane masks
 #define LZ_NC_LOADS \
             "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t" \
@@ -788,7 +793,7 @@ struct DevWave {
             "s_add_i32 %[t0], %[gap], 1\n\t" \
             "s_min_u32 %[t0], %[t0], 63\n\t" \
             "s_bfm_b64 %[m], %[t0], 0\n\t" \
-            "s_and_b64 %[m], %[m], %[seed]\n\t"
+            "s_and_b64 %[m], %[m], %[seed]\n\t" LZ_NC_NOSEED
         // the null event: the machine's state after it (see PairMachine::run)
 #define LZ_NC_COMMIT \
             "s_sub_i32 %[plit], %[t1], %[kb]\n\t"           /* what is left of the literals before the backward extension */ \

@@ -169,6 +169,36 @@ int lzani_comm_gatherv(lzani_ctx* c, const void* d_send, void* d_recv, const uin
 
 // ---- one process, n GPUs ------------------------------------------------------------------------------
 static int gfail(lzani_group* g, int code, const std::string& msg) { if (g) g->err = msg; return code; }
+static thread_local std::string t_group_create_err;      // why the last lzani_group_create of this thread failed (there is no group to hold it)
+
+// The shard bookkeeping of lzani_group_run_rows as a pure host function (exported so that it can be tested without a
+// GPU): rows keep their order inside a shard, shards follow each other in the gathered buffer; entry j of the scatter
+// table (j counts the rows shard by shard) says where the row's results sit in that buffer, where they belong in the
+// caller's CSR order, and how many there are.
+int lzani_plan_gather(uint32_t n_rows, const uint64_t* row_off, const uint32_t* part_of_row, uint32_t n_parts,
+                      uint64_t* shard_base, uint64_t* src, uint64_t* dst, uint64_t* cnt, uint32_t* row_of_entry)
+{
+    if (!n_parts || (n_rows && (!row_off || !part_of_row)) || !shard_base || (n_rows && (!src || !dst || !cnt))) return LZANI_ERR_ARG;
+    std::vector<u64> pairs(n_parts, 0);
+    for (u32 k = 0; k < n_rows; ++k) {
+        if (part_of_row[k] >= n_parts || row_off[k + 1] < row_off[k]) return LZANI_ERR_ARG;
+        pairs[part_of_row[k]] += row_off[k + 1] - row_off[k];
+    }
+    shard_base[0] = 0;
+    for (u32 d = 0; d < n_parts; ++d) shard_base[d + 1] = shard_base[d] + pairs[d];
+    std::vector<u64> at(shard_base, shard_base + n_parts);          // next free result of every shard
+    std::vector<u32> first(n_parts + 1, 0);                         // table entries of shard d: first[d] .. first[d + 1]
+    for (u32 k = 0; k < n_rows; ++k) ++first[part_of_row[k] + 1];
+    for (u32 d = 0; d < n_parts; ++d) first[d + 1] += first[d];
+    std::vector<u32> fill(first.begin(), first.end() - 1);
+    for (u32 k = 0; k < n_rows; ++k) {
+        const u32 d = part_of_row[k], j = fill[d]++;
+        src[j] = at[d]; dst[j] = row_off[k]; cnt[j] = row_off[k + 1] - row_off[k];
+        if (row_of_entry) row_of_entry[j] = k;
+        at[d] += cnt[j];
+    }
+    return LZANI_OK;
+}
 
 void lzani_group_destroy(lzani_group* g)
 {
@@ -178,11 +208,16 @@ void lzani_group_destroy(lzani_group* g)
     delete g;
 }
 
-const char* lzani_group_last_error(const lzani_group* g) { return g ? g->err.c_str() : "null group"; }
+// (a null group: the reason the last lzani_group_create of the calling thread failed, if it did)
+const char* lzani_group_last_error(const lzani_group* g)
+{
+    return g ? g->err.c_str() : (t_group_create_err.empty() ? "null group" : t_group_create_err.c_str());
+}
 
 int lzani_group_create(const lzani_params* p, uint32_t n_devices, const int* device_ids, lzani_group** out)
 {
-    if (!p || !out || !n_devices || !device_ids) return LZANI_ERR_ARG;
+    t_group_create_err.clear();
+    if (!p || !out || !n_devices || !device_ids) { t_group_create_err = "lzani_group_create: null argument"; return LZANI_ERR_ARG; }
     *out = nullptr;
     lzani_group* g = new (std::nothrow) lzani_group();
     if (!g) return LZANI_ERR_NOMEM;
@@ -190,7 +225,12 @@ int lzani_group_create(const lzani_params* p, uint32_t n_devices, const int* dev
     for (u32 d = 0; d < n_devices; ++d) {
         lzani_ctx* c = nullptr;
         int rc = lzani_create(p, device_ids[d], &c);
-        if (rc != LZANI_OK) { lzani_group_destroy(g); return rc; }
+        if (rc != LZANI_OK) {
+            t_group_create_err = "lzani_create on device " + std::to_string(device_ids[d]) + " failed with code " + std::to_string(rc) +
+                                 (rc == LZANI_ERR_PARAMS ? " (LZ parameters outside the supported envelope)" : rc == LZANI_ERR_DEVICE ? " (no such HIP device, or its stream could not be made)" : "");
+            lzani_group_destroy(g);
+            return rc;
+        }
         g->ctx.push_back(c);
     }
     std::vector<int> sorted(g->devs);
@@ -200,6 +240,7 @@ int lzani_group_create(const lzani_params* p, uint32_t n_devices, const int* dev
         g->comms.assign(n_devices, nullptr);
         ncclResult_t r = ncclCommInitAll(g->comms.data(), (int)n_devices, g->devs.data());
         if (r != ncclSuccess) {
+            t_group_create_err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
             g->comms.clear();
             lzani_group_destroy(g);
             return LZANI_ERR_DEVICE;
@@ -264,7 +305,10 @@ int lzani_group_run_rows(lzani_group* g, uint32_t n_rows, const uint32_t* ref_id
     for (u32 d = 1; d < nd; ++d) sh[d].base = sh[d - 1].base + sh[d - 1].off.back();
 
     // device 0 holds the gathered buffer (its own shard is written in place) and the CSR-ordered copy
-    HIPCHK(c0, hipSetDevice(c0->dev));
+    {
+        const hipError_t e = hipSetDevice(c0->dev);
+        if (e != hipSuccess) return gfail(g, LZANI_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    }
     DevBuf<int> d_all, d_final;
     if (hipMalloc(&d_all.p, std::max<u64>(n_pairs, 1) * 12) != hipSuccess || hipMalloc(&d_final.p, std::max<u64>(n_pairs, 1) * 12) != hipSuccess)
         return gfail(g, LZANI_ERR_NOMEM, "lzani_group_run_rows: result buffers on device 0");
@@ -317,16 +361,13 @@ int lzani_group_run_rows(lzani_group* g, uint32_t n_rows, const uint32_t* ref_id
     }
     if (ret == LZANI_OK && n_rows) {
         // shard order -> the caller's CSR order on device 0, then the one device-to-host copy
-        std::vector<u64> tab(3 * (size_t)n_rows);
-        u32 at = 0;
-        for (u32 d = 0; d < nd; ++d)
-            for (size_t i = 0; i < sh[d].rows.size(); ++i, ++at) {
-                tab[at] = sh[d].base + sh[d].off[i];
-                tab[n_rows + at] = row_off[sh[d].rows[i]];
-                tab[2 * (size_t)n_rows + at] = sh[d].off[i + 1] - sh[d].off[i];
-            }
+        std::vector<u64> tab(3 * (size_t)n_rows), sbase((size_t)nd + 1);
+        if (lzani_plan_gather(n_rows, row_off, part.data(), nd, sbase.data(), tab.data(), tab.data() + n_rows, tab.data() + 2 * (size_t)n_rows, nullptr) != LZANI_OK)
+            ret = gfail(g, LZANI_ERR_ARG, "lzani_group_run_rows: gather plan");
+        for (u32 d = 0; d < nd && ret == LZANI_OK; ++d)
+            if (sbase[d] != sh[d].base) ret = gfail(g, LZANI_ERR_STATE, "lzani_group_run_rows: gather plan and shards disagree");
         DevBuf<u64> d_tab;
-        hipError_t e = d_tab.alloc(tab.size());
+        hipError_t e = ret == LZANI_OK ? d_tab.alloc(tab.size()) : hipErrorInvalidValue;
         if (e == hipSuccess) e = hipMemcpyAsync(d_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c0->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_scatter_rows, dim3(n_rows), dim3(256), 0, c0->stream, d_all.p, d_final.p, d_tab.p, d_tab.p + n_rows, d_tab.p + 2 * (size_t)n_rows);
@@ -336,7 +377,8 @@ int lzani_group_run_rows(lzani_group* g, uint32_t n_rows, const uint32_t* ref_id
         if (e == hipSuccess && n_pairs) e = hipMemcpyAsync(out, d_final.p, n_pairs * 12, hipMemcpyDeviceToHost, c0->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
         for (u32 d = 1; d < nd && e == hipSuccess; ++d) { hipSetDevice(g->ctx[d]->dev); e = hipStreamSynchronize(g->ctx[d]->stream); }
-        if (e != hipSuccess) ret = gfail(g, LZANI_ERR_DEVICE, std::string("gather / copy out: ") + hipGetErrorString(e));
+        if (ret != LZANI_OK) {}                                   // (the gather plan failed: its message stands)
+        else if (e != hipSuccess) ret = gfail(g, LZANI_ERR_DEVICE, std::string("gather / copy out: ") + hipGetErrorString(e));
         else { float ms = 0; hipEventElapsedTime(&ms, e0, e1); g->gather_ms = ms; }
     }
     for (u32 d = 1; d < nd; ++d) if (d_shard[d]) { hipSetDevice(g->ctx[d]->dev); hipFree(d_shard[d]); }

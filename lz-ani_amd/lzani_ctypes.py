@@ -30,7 +30,7 @@ EXPORTS = ("lzani_default_params", "lzani_create", "lzani_destroy", "lzani_last_
            "lzani_debug_get_index", "lzani_run_rows_regions", "lzani_get_layout",
            "lzani_row_costs", "lzani_partition_rows", "lzani_comm_unique_id", "lzani_comm_init", "lzani_comm_allgather",
            "lzani_comm_gatherv", "lzani_group_create", "lzani_group_destroy", "lzani_group_last_error",
-           "lzani_group_set_genomes", "lzani_group_run_rows", "lzani_group_get_timing")
+           "lzani_group_set_genomes", "lzani_group_run_rows", "lzani_group_get_timing", "lzani_plan_gather")
 
 
 class LzaniError(RuntimeError):
@@ -100,6 +100,7 @@ def load_library():
         lib.lzani_group_set_genomes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.lzani_group_run_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.lzani_group_get_timing.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.lzani_plan_gather.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
         _lib = lib
     return _lib
 
@@ -134,6 +135,22 @@ def row_costs(ref_ids, row_off, query_ids, lens):
     if rc != 0:
         raise LzaniError(f"lzani_row_costs: {ERRORS.get(rc, rc)}")
     return cost
+
+
+def plan_gather(row_off, part_of_row, n_parts):
+    """Shard bookkeeping of lzani_group_run_rows (lzani_plan_gather; no GPU needed): shard_base[n_parts + 1] and the
+    scatter table src / dst / cnt / row_of_entry, one entry per row, shard by shard."""
+    lib = load_library()
+    row_off = np.ascontiguousarray(row_off, dtype=np.uint64)
+    part = np.ascontiguousarray(part_of_row, dtype=np.uint32)
+    n = len(part)
+    base = np.zeros(n_parts + 1, dtype=np.uint64)
+    src, dst, cnt = (np.zeros(n, dtype=np.uint64) for _ in range(3))
+    row = np.zeros(n, dtype=np.uint32)
+    rc = lib.lzani_plan_gather(n, _ptr(row_off), _ptr(part), n_parts, _ptr(base), _ptr(src), _ptr(dst), _ptr(cnt), _ptr(row))
+    if rc != 0:
+        raise LzaniError(f"lzani_plan_gather: {ERRORS.get(rc, rc)}")
+    return base, src, dst, cnt, row
 
 
 def partition_rows(n_rows, n_parts, row_cost=None):

@@ -195,3 +195,55 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity_on_last_slab"] == "bit-exact"
     assert d["config"]["pairs_timed"] == 3 * 50 * 239 and d["config"]["pairs_timed_rank0"] == 3 * 25 * 239
+
+
+def test_group_gather_plan_against_python_statement():
+    """The shard bookkeeping of lzani_group_run_rows (lzani_plan_gather, a pure host function of the C-ABI) against
+    a Python statement of the same rule, for ragged rows with empty rows, empty shards and more shards than rows:
+    shards are contiguous in the gathered buffer in shard order, rows keep their order inside a shard, and the
+    scatter table moves every row's results to its place in the caller's CSR order (simulated here on arrays)."""
+    st = SG.Stream(91)
+    cases = []
+    for n_rows, n_parts in ((0, 3), (1, 4), (5, 8), (37, 2), (200, 8), (64, 3)):
+        sizes = [0 if st.one() < 0.15 else st.randint(1, 40) for _ in range(n_rows)]
+        part = [st.randint(0, n_parts - 1) for _ in range(n_rows)]
+        cases.append((sizes, part, n_parts))
+    cases.append(([3, 0, 7, 2], [2, 2, 2, 2], 4))               # every row on one shard, three shards empty
+    cases.append(([5] * 12, [k % 8 for k in range(12)], 8))     # the cyclic deal of dense rows
+    for sizes, part, n_parts in cases:
+        n_rows = len(sizes)
+        row_off = np.zeros(n_rows + 1, dtype=np.uint64)
+        row_off[1:] = np.cumsum(sizes)
+        base, src, dst, cnt, row = L.plan_gather(row_off, np.array(part, dtype=np.uint32), n_parts)
+        # the rule, restated
+        want_base = [0]
+        for d in range(n_parts):
+            want_base.append(want_base[-1] + sum(s for s, p in zip(sizes, part) if p == d))
+        assert base.tolist() == want_base
+        j = 0
+        for d in range(n_parts):
+            at = want_base[d]
+            for k in range(n_rows):
+                if part[k] != d:
+                    continue
+                assert (int(src[j]), int(dst[j]), int(cnt[j]), int(row[j])) == (at, int(row_off[k]), sizes[k], k), (d, k)
+                at += sizes[k]
+                j += 1
+        assert j == n_rows
+        # what the devices and the scatter kernel do with it: shard d computes its rows in order into its part of the
+        # gathered buffer; the table then restores the CSR order
+        n_pairs = int(row_off[-1])
+        csr = np.arange(n_pairs, dtype=np.int64) * 7 + 1            # a distinct value per pair, in the caller's order
+        gathered = np.full(n_pairs, -1, dtype=np.int64)
+        for d in range(n_parts):
+            at = want_base[d]
+            for k in range(n_rows):
+                if part[k] == d:
+                    gathered[at:at + sizes[k]] = csr[int(row_off[k]):int(row_off[k + 1])]
+                    at += sizes[k]
+        final = np.full(n_pairs, -2, dtype=np.int64)
+        for j in range(n_rows):
+            final[int(dst[j]):int(dst[j]) + int(cnt[j])] = gathered[int(src[j]):int(src[j]) + int(cnt[j])]
+        assert np.array_equal(final, csr)
+    with pytest.raises(L.LzaniError):
+        L.plan_gather(np.array([0, 2], np.uint64), np.array([5], np.uint32), 2)        # a shard number out of range

@@ -572,6 +572,37 @@ def test_join_form_of_candidate_detection(monkeypatch):
             e += 1
 
 
+def test_fuzz_medium_block_and_bitmap_kernels(monkeypatch):
+    """The differential fuzz of tools/fuzz_gpu.py at 8-70 kbp (random parameters in three cases out of four, N runs,
+    inversions), 20 seeded cases, each through three forms of the pair path: the default one (4 dense rows: the wave
+    kernel with a probe per position), rows of 135 pairs through the block kernel with the LDS filter, and dense rows
+    with their candidates from the presence matrix (forced from one row on)."""
+    st = SG.Stream(20260)
+    blk = pmx = 0
+    for case in range(20):
+        prm, seqs = U.fuzz_case_medium(st)
+        want = O.oracle_all2all(seqs, prm, threads=16)
+        eng = L.Engine(prm)
+        eng.set_genomes(seqs)
+        assert np.array_equal(eng.all2all(), want), (case, prm)
+        monkeypatch.setenv("LZANI_PM_MIN_ROWS", "1")
+        got = eng.all2all()
+        pmx += eng.layout()["bitmap_launches"]
+        monkeypatch.delenv("LZANI_PM_MIN_ROWS")
+        assert np.array_equal(got, want), ("bitmaps", case, prm)
+        n = len(seqs)
+        qs = [[x for x in range(n) if x != r] * 45 for r in range(n)]
+        row_off = np.zeros(n + 1, np.uint64)
+        row_off[1:] = np.cumsum([len(x) for x in qs])
+        monkeypatch.setenv("LZANI_BLOCK_KERNEL", "1")
+        out = eng.run_rows(np.arange(n, dtype=np.uint32), row_off, np.array([x for row in qs for x in row], np.uint32)).reshape(-1, 3)
+        blk += eng.layout()["block_launches"]
+        monkeypatch.delenv("LZANI_BLOCK_KERNEL")
+        eng.close()
+        assert np.array_equal(out, np.concatenate([want[r, qs[r]] for r in range(n)])), ("block kernel", case, prm)
+    assert blk >= 10 and pmx >= 10, (blk, pmx)       # (both need tag words: not every random parameter set has them)
+
+
 def test_presence_matrix_candidates(monkeypatch):
     """Dense rows: the candidates of every pair come from per-pair bitmaps made ahead from the presence matrix of the
     batch's references (k_pm_build, k_pm_cand) and the pair kernel reads them 64 positions per lane: whole matrices

@@ -16,7 +16,7 @@ st = SG.Stream(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
 medium = len(sys.argv) > 3 and sys.argv[3] == "medium"
 large = len(sys.argv) > 3 and sys.argv[3] == "large"
-t0, it, bad, blk = time.time(), 0, 0, 0
+t0, it, bad, blk, pmx = time.time(), 0, 0, 0, 0
 while time.time() - t0 < budget:
     it += 1
     prm, seqs = U.fuzz_case_large(st) if large else U.fuzz_case_medium(st) if medium else U.fuzz_case(st)
@@ -27,6 +27,14 @@ while time.time() - t0 < budget:
     if not np.array_equal(got, want):
         bad += 1
         print("MISMATCH", prm, [len(s) for s in seqs], np.argwhere((got != want).any(axis=2))[:3].tolist(), flush=True)
+    if medium or large:                               # dense rows with their candidates from the presence matrix (by default from 32 rows on)
+        os.environ["LZANI_PM_MIN_ROWS"] = "1"
+        got2 = eng.all2all()
+        del os.environ["LZANI_PM_MIN_ROWS"]
+        pmx += eng.layout()["bitmap_launches"]
+        if not np.array_equal(got2, want):
+            bad += 1
+            print("PM MISMATCH", prm, [len(s) for s in seqs], np.argwhere((got2 != want).any(axis=2))[:3].tolist(), flush=True)
     if medium:                                        # rows of >= 128 pairs (every query 45 times): the block kernel with the LDS filter
         n = len(seqs)
         ref_ids = np.arange(n, dtype=np.uint32)
@@ -62,5 +70,5 @@ while time.time() - t0 < budget:
     eng.close()
     if it % 500 == 0:
         print("...", it, "cases", flush=True)
-print("cases", it, "mismatches", bad, "block-kernel launches", blk)
+print("cases", it, "mismatches", bad, "block-kernel launches", blk, "bitmap-fed launches", pmx)
 sys.exit(1 if bad else 0)

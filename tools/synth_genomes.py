@@ -94,45 +94,46 @@ def make_set(n, seed, lmin=36000, lmax=44000, fam=10, dmin=0.01, dmax=0.15):
     return names, seqs
 
 
+def _generator_version():
+    """Hash of the generator's own source: a cached set made by an older mutate/make_set is never served."""
+    import hashlib, inspect
+    src = "".join(inspect.getsource(f) for f in (Stream, mutate, make_set))
+    return hashlib.sha256(src.encode()).hexdigest()[:12]
+
+
 def make_set_cached(n, seed, cache_dir=None, **kw):
-    """make_set through an on-disk cache (one .npz per argument set): the 10,000-genome bench set takes ~1 min
-    to generate, and a profiling session runs the bench many times on one box."""
-    import os
-    cache_dir = cache_dir or os.environ.get("LZANI_SYNTH_CACHE", "/tmp/lzani_synth_cache")
-    key = "set_n%d_s%d_%s.npz" % (n, seed, "_".join("%s%s" % (k, kw[k]) for k in sorted(kw)))
+    """make_set through an on-disk cache (one .npz per argument set and generator version): the 10,000-genome bench
+    set takes ~1 min to generate, and a profiling session runs the bench many times on one box.  The cache lives in a
+    per-user directory (LZANI_SYNTH_CACHE, else $XDG_CACHE_HOME/lzani_synth, else ~/.cache/lzani_synth, else a
+    uid-suffixed directory under /tmp); an entry carries a checksum of its codes and is regenerated when it does not
+    verify."""
+    import os, zlib
+    cache_dir = cache_dir or os.environ.get("LZANI_SYNTH_CACHE")
+    if not cache_dir:
+        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        cache_dir = os.path.join(base, "lzani_synth")
+        try:
+            os.makedirs(cache_dir, mode=0o700, exist_ok=True)
+        except OSError:
+            cache_dir = "/tmp/lzani_synth_cache_%d" % os.getuid()
+    key = "set_n%d_s%d_%s_g%s.npz" % (n, seed, "_".join("%s%s" % (k, kw[k]) for k in sorted(kw)), _generator_version())
     path = os.path.join(cache_dir, key)
     try:
         z = np.load(path)
         off, codes = z["off"], z["codes"]
-        seqs = [codes[off[i]:off[i + 1]] for i in range(n)]
-        return [str(x) for x in z["names"]], seqs
-    except Exception:
-        pass
+        if len(off) == n + 1 and int(z["crc"]) == zlib.crc32(codes.tobytes()):
+            return [str(x) for x in z["names"]], [codes[off[i]:off[i + 1]] for i in range(n)]
+    except (OSError, KeyError, ValueError, EOFError):
+        pass                                   # no entry, or not one of ours: generate (and replace it)
     names, seqs = make_set(n, seed, **kw)
     try:
-        os.makedirs(cache_dir, exist_ok=True)
+        os.makedirs(cache_dir, mode=0o700, exist_ok=True)
         off = np.zeros(n + 1, dtype=np.int64)
         off[1:] = np.cumsum([len(s) for s in seqs])
+        codes = np.concatenate(seqs) if n else np.zeros(0, np.uint8)
         tmp = path + ".%d.tmp.npz" % os.getpid()
-        np.savez(tmp, off=off, codes=np.concatenate(seqs) if n else np.zeros(0, np.uint8), names=np.array(names))
+        np.savez(tmp, off=off, codes=codes, names=np.array(names), crc=np.uint32(zlib.crc32(codes.tobytes())))
         os.replace(tmp, path)
-    except Exception:
-        pass
+    except OSError:
+        pass                                   # (a read-only or full cache directory only costs the next run its minute)
     return names, seqs
-
-
-def write_fasta(path, names, seqs, width=70):
-    lut = np.frombuffer(b"ACGTNN", dtype=np.uint8)
-    with open(path, "wb") as f:
-        for nm, s in zip(names, seqs):
-            f.write(b">" + nm.encode() + b"\n")
-            txt = lut[np.minimum(s, 5)].tobytes()
-            for k in range(0, len(txt), width):
-                f.write(txt[k:k + width] + b"\n")
-
-
-if __name__ == "__main__":
-    import sys
-    n, seed, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-    names, seqs = make_set(n, seed)
-    write_fasta(out, names, seqs)
