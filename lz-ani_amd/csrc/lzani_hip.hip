@@ -63,6 +63,7 @@ struct lzani_ctx {
     u64 total_nm = 0;
     bool kmers_ready = false;
     bool km_timed = false;        // the last run made the k-mer words (ev_km holds their stamps)
+    double join_ms_pending = 0;   // ... and / or the join lists: their time, added to that run's kmers_ms
     hipEvent_t ev_km[2] = {nullptr, nullptr};
     bool all_nfree = false;       // no genome holds an N: the NFREE kernel instantiation applies
 
@@ -161,10 +162,13 @@ void free_genomes(lzani_ctx* c)
     c->d_t2 = c->d_nm = c->d_nmoff = nullptr; c->d_L = nullptr; c->d_kmL = c->d_kmS = nullptr; c->kmers_ready = false;
     c->n = 0;
 }
-void free_slabs(lzani_ctx* c)
+void free_pm(lzani_ctx* c)
 {
     hipFree(c->d_pm); hipFree(c->d_pm_cbits);
     c->d_pm = c->d_pm_cbits = nullptr; c->pm_bytes = c->pm_cbits_bytes = 0;
+}
+void free_slabs(lzani_ctx* c)
+{
     hipFree(c->d_dirz); hipFree(c->d_ent); hipFree(c->d_bk); hipFree(c->d_tw); hipFree(c->d_fl); hipFree(c->d_status);
     c->d_fl = nullptr;
     hipFree(c->d_ikeys_in); hipFree(c->d_ikeys); hipFree(c->d_icnt); hipFree(c->d_ibase);
@@ -356,11 +360,32 @@ int ensure_kmers(lzani_ctx* c)
     }
     HIPCHK(c, hipGetLastError());
     c->tm.index_launches += 1;
-    if (c->join_mode) { int rc = build_join_lists(c); if (rc) return rc; }
     HIPCHK(c, hipEventRecord(c->ev_km[1], c->stream));
     c->kmers_ready = true;
     c->km_timed = true;
     return LZANI_OK;
+}
+
+// The sorted join lists of a long-genome set (join form of candidate detection): made by the first run that needs them
+// -- dense rows take their candidates from the presence matrix instead -- and kept like the k-mer words they are made
+// from; their time is part of that run's kmers_ms.
+int ensure_join(lzani_ctx* c)
+{
+    if (!c->join_mode || c->join_ready) return LZANI_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(c, hipEventCreate(&e0));
+    hipError_t e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    int rc = e == hipSuccess ? build_join_lists(c) : fail(c, LZANI_ERR_DEVICE, std::string("join lists: ") + hipGetErrorString(e));
+    if (rc == LZANI_OK) {
+        float ms = 0;
+        if (hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+            c->join_ms_pending = ms;
+        c->join_ready = true;
+    }
+    hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    return rc;
 }
 
 // Index build of `rows` references (device list d_ref_ids) into slots 0..rows-1.
@@ -473,53 +498,63 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     c->km_timed = false;
     int rc = ensure_kmers(c);
     if (rc) return rc;
-    rc = ensure_slabs(c, n_rows);
-    if (rc) return rc;
-
     // Dense rows: the candidates of every pair of a batch come from the presence matrix of its references
-    // (lzani_kernels_cand.h) instead of a probe per query position; a batch is then also bounded by what the candidate
-    // bitmaps of its pairs take.
-    u32 bs = c->slots;                                       // rows per batch
+    // (lzani_kernels_cand.h) instead of a probe per query position (viral sizes) or a join of sorted k-mer lists per pair
+    // (long genomes); a batch is then also bounded by what the candidate bitmaps of its pairs take, and the index slabs
+    // are sized for such a batch.
     bool pm = false;
     u64 cb_words = 0;                                        // 32-bit words of one pair's candidate bitmap
-    u32 pm_tiles = 0;
-    const int pm_bits = std::min(c->geo.kb, 24);
+    u32 pm_tiles = 0, pm_group = PM_GROUP;
+    const int pm_bits = std::min(c->geo.kb, 30);             // exact up to mal 15: the mixer is a bijection on the key bits
+    u32 want_rows = n_rows;
+    size_t pm_per_row = 0;
     {
         const char* e = getenv("LZANI_PM");
         const char* mn = getenv("LZANI_PM_MIN_ROWS");
         const char* mb = getenv("LZANI_PM_MAX_BYTES");
         const u32 min_rows = mn ? (u32)std::max(1, atoi(mn)) : 32u;
-        pm = !rs && !query_ids && c->d_kmL && c->tw_stride && !c->join_mode && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 24 &&
+        pm = !rs && !query_ids && c->d_kmL && c->tw_stride && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 30 &&
              c->n >= 2 && n_rows >= min_rows && !(e && *e == '0');
         if (pm) {
             int Lmax = 0;
             for (u32 g = 0; g < c->n; ++g) Lmax = std::max(Lmax, c->L[g]);
             pm_tiles = (u32)(((u64)Lmax + c->P.mrd + 320 + PM_TILE - 1) / PM_TILE);
             cb_words = (u64)pm_tiles * PM_TILE_WORDS;
-            const size_t m_bytes = ((size_t)1 << pm_bits) * (PM_GROUP / 8);
-            if (c->pm_bytes < m_bytes) {
-                hipFree(c->d_pm); c->d_pm = nullptr; c->pm_bytes = 0;
-                HIPCHK(c, hipMalloc(&c->d_pm, m_bytes));
-                c->pm_bytes = m_bytes;
-            }
-            const size_t per_row = (size_t)(c->n - 1) * cb_words * 4;
+            pm_group = pm_bits <= 24 ? (u32)PM_GROUP : 128u;                      // 64-byte rows up to 2^24 of them, 16-byte rows beyond (16 GB at 2^30)
+            const size_t m_bytes = ((size_t)1 << pm_bits) * (pm_group / 8);
+            pm_per_row = (size_t)(c->n - 1) * cb_words * 4;
+            const size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride) + (c->sort_build ? (size_t)16 * c->Tmax + 16 : 0);
             size_t free_b = 0, total_b = 0;
             HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-            const size_t cap = mb ? (size_t)strtoull(mb, nullptr, 10) : ((size_t)32 << 30);
-            const size_t budget = std::min(cap, (size_t)((free_b + c->pm_cbits_bytes) * 0.7));
-            u64 fit = budget / per_row;
+            const size_t pool = free_b + (size_t)c->slots * per_slot + c->pm_cbits_bytes + c->pm_bytes;   // what this run may lay out anew
+            const size_t cap = mb ? (size_t)strtoull(mb, nullptr, 10) : std::min((size_t)64 << 30, total_b / 4);
+            u64 fit = (size_t)(pool * 0.85) > m_bytes ? ((size_t)(pool * 0.85) - m_bytes) / (per_slot + pm_per_row) : 0;
+            fit = std::min<u64>(fit, cap / pm_per_row);
             fit = std::min<u64>(fit, 0xFFFFFFF0ull / (u64)(c->n - 1));             // pair indexes of a batch are 32 bits
-            if (fit < 8) pm = false;                          // (a genome set this large: the probe form, batch by batch)
+            if (fit < 8) pm = false;                          // (a genome set this large: the probe / join form, batch by batch)
             else {
-                bs = (u32)std::min<u64>(bs, fit);
-                if (bs < n_rows && bs > PM_GROUP) bs -= bs % PM_GROUP;       // several batches: whole groups
-                const size_t need = (size_t)std::min(bs, n_rows) * per_row;
-                if (c->pm_cbits_bytes < need) {
-                    hipFree(c->d_pm_cbits); c->d_pm_cbits = nullptr; c->pm_cbits_bytes = 0;
-                    HIPCHK(c, hipMalloc(&c->d_pm_cbits, need));
-                    c->pm_cbits_bytes = need;
+                want_rows = (u32)std::min<u64>(n_rows, fit);
+                if (c->pm_bytes < m_bytes) {
+                    hipFree(c->d_pm); c->d_pm = nullptr; c->pm_bytes = 0;
+                    HIPCHK(c, hipMalloc(&c->d_pm, m_bytes));
+                    c->pm_bytes = m_bytes;
                 }
             }
+        }
+    }
+    const bool use_join = c->join_mode && !pm;
+    if (use_join) { rc = ensure_join(c); if (rc) return rc; }          // (before the slabs are sized: they take 60 % of what is left)
+    rc = ensure_slabs(c, want_rows);
+    if (rc) return rc;
+    u32 bs = c->slots;                                       // rows per batch
+    if (pm) {
+        bs = std::min(bs, want_rows);
+        if (bs < n_rows && bs > pm_group) bs -= bs % pm_group;           // several batches: whole groups
+        const size_t need = (size_t)std::min(bs, n_rows) * pm_per_row;
+        if (c->pm_cbits_bytes < need) {
+            hipFree(c->d_pm_cbits); c->d_pm_cbits = nullptr; c->pm_cbits_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->d_pm_cbits, need));
+            c->pm_cbits_bytes = need;
         }
     }
 
@@ -592,7 +627,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     const char* const bkenv = getenv("LZANI_BLOCK_KERNEL");
     DevBuf<unsigned long long> d_cbits;                      // join form: one candidate bitmap per resident wave
     u64 cbits_stride = 0;
-    if (c->join_mode && !rs) {
+    if (use_join && !rs) {
         int Lmax = 0;
         for (u32 g = 0; g < c->n; ++g) Lmax = std::max(Lmax, c->L[g]);
         cbits_stride = (u64)((Lmax + c->P.mrd) >> 6) + 8;
@@ -613,11 +648,11 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         HIPCHK(c, hipEventRecord(ev[1], c->stream));
         if (pm && e1 > e0) {
             // candidate bitmaps of the batch's pairs, group by group of PM_GROUP references
-            for (u32 g0 = 0; g0 < rows; g0 += PM_GROUP) {
+            for (u32 g0 = 0; g0 < rows; g0 += pm_group) {
                 PmArgs pg;
                 pg.G = gtab(c);
                 pg.ref_ids = d_ref + k0; pg.row_off = d_off + k0;
-                pg.slot0 = g0; pg.rows = std::min<u32>(PM_GROUP, rows - g0);
+                pg.slot0 = g0; pg.rows = std::min<u32>(pm_group, rows - g0);
                 pg.M = c->d_pm; pg.rw = ((pg.rows + 127) / 128) * 4; pg.mmask = (u32)lowmask(pm_bits);
                 pg.mal = c->P.mal; pg.mrd = c->P.mrd;
                 pg.cbits = c->d_pm_cbits; pg.cb_words = cb_words; pg.e0 = e0; pg.n = c->n; pg.q0 = 0;
@@ -778,6 +813,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev_km[0], c->ev_km[1]));
         c->tm.kmers_ms = ms;
     }
+    c->tm.kmers_ms += c->join_ms_pending;
+    c->join_ms_pending = 0;
     for (u32 b = 0; b < n_batches; ++b) {
         hipEvent_t* ev = c->events.data() + (size_t)EV * b;
         float ms = 0;
@@ -838,6 +875,7 @@ void lzani_destroy(lzani_ctx* c)
     comm_release(c);
     free_genomes(c);
     free_slabs(c);
+    free_pm(c);
     hipFree(c->d_cursor);
     hipFree(c->d_blkctr);
     for (auto& e : c->events) if (e) hipEventDestroy(e);
@@ -855,6 +893,7 @@ int lzani_set_genomes(lzani_ctx* c, uint32_t n, const uint8_t* const* codes, con
     HIPCHK(c, hipSetDevice(c->dev));
     free_genomes(c);
     free_slabs(c);
+    free_pm(c);
     c->L.resize(n);
     c->nmoff.resize(n);
     std::vector<u64> codeoff(n);

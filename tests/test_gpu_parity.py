@@ -507,7 +507,7 @@ def test_full_size_10k_genomes():
             assert tuple(flat[r, q if q < r else q - 1]) == O.oracle_pair(seqs[r], seqs[q]), (r, q)
 
 
-def test_bacterial_geometry_5mbp():
+def test_bacterial_geometry_5mbp(monkeypatch):
     """BASELINE configs[3] at its own geometry: 5 Mbp genomes with --mal 15 --msl 9 --reg 60 -> 30 key bits, 2^24
     buckets, 24-bit positions, 6 tag bits, i.e. tag words + a 256 MB bucket table per slab and the
     global-atomics index build; the whole 5 x 5 matrix against the oracle."""
@@ -522,9 +522,16 @@ def test_bacterial_geometry_5mbp():
     assert (lay["key_bits"], lay["dir_bits"], lay["pos_bits"], lay["tag_mask"]) == (30, 24, 24, 0x3F)
     assert lay["kmer_words"] == 1 and lay["bucket_table"] == 1 and lay["tag_words"] == 1 and lay["join_lists"] == 1
     got = eng.all2all()
-    assert eng.layout()["bytes_per_slot"] > 400 << 20
+    assert eng.layout()["bytes_per_slot"] > 400 << 20 and eng.layout()["bitmap_launches"] == 0      # (5 rows: candidates by the join)
+    # the same matrix with the candidates from the presence matrix, as dense runs of 32 rows and more take them: 2^30 rows
+    # of 16 bytes for a group of up to 128 references, the pair's bitmap 690 KB
+    monkeypatch.setenv("LZANI_PM_MIN_ROWS", "1")
+    got_pm = eng.all2all()
+    assert eng.layout()["bitmap_launches"] == 1
+    monkeypatch.delenv("LZANI_PM_MIN_ROWS")
     eng.close()
     want = O.oracle_all2all(seqs, prm, threads=16)
+    assert np.array_equal(got_pm, want)
     bad = np.argwhere((got != want).any(axis=2))
     assert len(bad) == 0, (bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
     assert got[0, 1, 0] > 4_500_000 and got[3, 4, 0] > 4_000_000 and got[0, 3, 0] < 1_000_000
