@@ -747,7 +747,13 @@ struct PairMachine {
                 // else touched; what it leaves unfinished it hands back (the round done, or the event found).
                 if (trk & (lit == 0)) {
                     int last_cl = 0, last_clit = 0;
+#if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
+                    w.cycles_mark(-1);                                 // wave cycles by what the chain handed back: closes the open interval
+#endif
                     in_hand = w.null_chain(i, r_end, prev_rs, prev_re, pre_lit, last_cl, last_clit, adv, bpos, blen);
+#if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
+                    w.cycles_mark(in_hand);
+#endif
                     if (last_cl) { g.cl = last_cl; g.clit = last_clit; g.nl = 0; }  // discard + the match (+ forward extension) of the last event
                 }
             }

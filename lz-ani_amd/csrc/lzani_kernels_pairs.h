@@ -57,7 +57,23 @@ struct DevWave {
     u32 a_ref = 0;
 #ifdef LZANI_CHAIN_STATS
     unsigned st[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // diagnostic build: chain calls, commits, exits by kind, events by the general path, refills
+    // wave cycles between two null_chain calls by what the first one handed back (0 nothing, 1 round done, 2 event found),
+    // slot 3 = inside null_chain itself; stc_open = the slot the running interval belongs to
+    unsigned long long stc[4] = {0, 0, 0, 0}, stc_t0 = 0;
+    int stc_open = -2;
+    __device__ __forceinline__ void cycles_mark(int code)
+    {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        if (stc_open == 0) stc[0] += t - stc_t0; else if (stc_open == 1) stc[1] += t - stc_t0; else if (stc_open == 2) stc[2] += t - stc_t0; else if (stc_open == 3) stc[3] += t - stc_t0;
+        stc_open = code < 0 ? 3 : code;
+        stc_t0 = t;
+    }
 #endif
+    // null_chain found the queue short of what it needs -- empty, or ending inside the tracking steps of i -- with more
+    // of the pair's bitmap to read: the next find_event call only refills (from i, if queued candidates are left)
+    bool refill_only = false;
+    int restart_at = -1;         // the last i a refill restarted the detection at (no second restart at the same place)
     // the tracking round null_chain has done for the next find_event call (CHAIN)
     bool pre_round = false;
     u64 pre_seed = 0;
@@ -951,6 +967,13 @@ struct DevWave {
 #undef LZ_NC_SEEDS
 #undef LZ_NC_COMMIT
         q_head = qh;
+        if constexpr (JOIN) {
+            // Nothing in hand because the queue ran out (or its tail does not cover the 41 steps behind i) while the pair's
+            // bitmap has more: refill first and come back -- the round is then this loop's, not the compiler's, and a
+            // queue tail costs no wave-wide detection of its own (find_event's light round stays for the scan that
+            // has jumped over the queue: related stretches).
+            if (code == 0 && scan_pos >= i && scan_pos < iend && (qh >= q_cnt || (i > ilim && restart_at != i))) refill_only = true;
+        }
         pre_round = code == 1;
         pre_seed = seed; pre_rk0 = rk0; pre_rk1 = rk1; pre_qk = qk;
         if (code == 2) { adv = ap - i; last_src = q_head++; }
@@ -968,7 +991,10 @@ struct DevWave {
         // tracking steps of this call (the machine clears trk once lit > mqd); one lane per tracking step
         const int nt = trk ? imin(imin(n, P.mqd - lit + 1), 64) : 0;
         if (q_head < q_cnt && __builtin_amdgcn_readlane(a_pos, q_head) < i) drop_before(i);
-        bool refill_now = scan_pos < i + nt;                         // the queue must cover the tracking steps
+        const bool only = CHAIN && JOIN && refill_only;              // (see null_chain)
+        refill_only = false;
+        if (only && q_head < q_cnt) { scan_pos = i; restart_at = i; }        // the queue's tail: detected again, with what follows it
+        bool refill_now = only || scan_pos < i + nt;                 // the queue must cover the tracking steps
         bool round_done = !trk;
         u32 rk0 = KM_INVALID, rk1 = KM_INVALID, qk = KM_INVALID;
         u64 seedmask = 0;
@@ -994,7 +1020,7 @@ struct DevWave {
         }
         int pos = i, guard = 0;
         bool merge_done = false;
-        if (trk & refill_now) {
+        if (trk & refill_now & !only) {
             // A tracking round the queue does not cover (the scan has jumped over it: an extension moved, a related
             // stretch) runs LIGHT, on its own: its anchors are detected for the tracking steps alone and verified by the
             // wave one at a time, only at the steps the round really reaches (as find_event_round does) -- resolving 64
@@ -1044,6 +1070,7 @@ struct DevWave {
                 if (++guard > (1 << 24)) { LZ_GUARD_TRIP(7); break; }
                 refill(pos);
                 refill_now = false;
+                if (only) { adv = 0; return false; }                 // (nothing looked at: the machine comes back at once)
             }
             if (!round_done) { seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk); round_done = true; }
             if (!merge_done) {
@@ -1275,6 +1302,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     m.run(res);
 #ifdef LZANI_CHAIN_STATS
     for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[k], lane == 0 ? (unsigned long long)w.st[k] : 0ULL);
+    for (int k = 0; k < 4; ++k) atomicAdd(&g_chain_stats[8 + k], lane == 0 ? w.stc[k] : 0ULL);
 #endif
 #ifdef LZANI_STAMPS
     w.stamp(0);

@@ -475,9 +475,9 @@ def test_full_size_10k_genomes():
     lay = eng.layout()
     eng.close()
     # dense rows take their candidates from per-pair bitmaps (presence matrix of the batch's references): a batch is
-    # bounded by the bitmaps of its pairs -- 512 rows of 9,999 pairs -- and every batch is one bitmap-fed launch
+    # bounded by the bitmaps of its pairs -- 64 GB = 1,024 rows of 9,999 pairs -- and every batch is one bitmap-fed launch
     assert lay["tag_words"] == 1 and lay["n_free"] == 1
-    assert lay["bitmap_launches"] == lay["batches_last_run"] == 20 and lay["block_launches"] == 0
+    assert lay["bitmap_launches"] == lay["batches_last_run"] and 2 <= lay["batches_last_run"] <= 40 and lay["block_launches"] == 0
     mat, lit, comp = flat[..., 0], flat[..., 1], flat[..., 2]
     assert flat.min() >= 0
     assert np.array_equal(comp == 0, (mat == 0) & (lit == 0))
