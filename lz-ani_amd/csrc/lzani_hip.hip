@@ -512,8 +512,11 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         const char* e = getenv("LZANI_PM");
         const char* mn = getenv("LZANI_PM_MIN_ROWS");
         const char* mb = getenv("LZANI_PM_MAX_BYTES");
-        const u32 min_rows = mn ? (u32)std::max(1, atoi(mn)) : 32u;
-        pm = !rs && !query_ids && c->d_kmL && c->tw_stride && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 30 &&
+        // (from 32 rows on where the probe form with tag words is the alternative; from 8 rows where it is the rounds of the
+        // first kernel: genomes whose tags do not fit a tag byte -- 260 kbp to 2 Mbp at mal 15, viral sizes at mal 13+.
+        // Below, the matrix -- 16 GB to clear at 30 key bits -- costs more than it saves.)
+        const u32 min_rows = mn ? (u32)std::max(1, atoi(mn)) : c->tw_stride ? 32u : 8u;
+        pm = !rs && !query_ids && c->d_kmL && c->bk_stride && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 30 &&
              c->n >= 2 && n_rows >= min_rows && !(e && *e == '0');
         if (pm) {
             int Lmax = 0;

@@ -522,19 +522,30 @@ struct DevWave {
 #pragma unroll
         for (int k = 0; k < 2 * AQ_LDS_CAND; k += 64) cq[k + lane] = 0;     // the seed bitmap is all zero between rounds
         lds_order();
-        if (JOIN) {                                        // join form: the bitmap says where, not which bucket slot
+        bool simple, dead = false;
+        int pos;
+        if (JOIN) {
+            // bitmap form: the bitmap says where, not which bucket slot -- the candidate's bucket (its first four entries,
+            // 16 bytes) is read whole and the entry carrying the tag picked from it: one dependent load instead of tag word
+            // + entry, and no tag-word table needed (tags of any width: mid-size genomes with long k-mers)
             const u32 hq = qkL[(u32)qp];
             const bool ok = live & (hq != KM_INVALID);
-            const u32 w = I.tw[ok ? hq >> tb : 0u];
-            const u32 x = w ^ rep4(0x80u | (hq & I.tagmask));
-            const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
-            const bool cplx = (w == TW_OVERFLOW) | ((z & (z - 1)) != 0) | (z == 0);
-            slot = (!ok | cplx) ? (u32)AQ_COMPLEX : 4u * (hq >> tb) + ((u32)__builtin_ctz(z | 0x80000000u) >> 3);
+            const uint4 bkv = reinterpret_cast<const uint4*>(I.bk)[ok ? hq >> tb : 0u];
+            const u32 tag = hq & I.tagmask;                  // (BK_EMPTY / BK_OVERFLOW never carry a real tag: tag + position bits <= 30)
+            const bool m0 = (bkv.x >> I.posbits) == tag, m1 = (bkv.y >> I.posbits) == tag, m2 = (bkv.z >> I.posbits) == tag,
+                       m3 = (bkv.w >> I.posbits) == tag;
+            const int cnt = (int)m0 + (int)m1 + (int)m2 + (int)m3;
+            const bool ovf = bkv.w == BK_OVERFLOW;
+            simple = ok & !ovf & (cnt == 1);                 // the tag in two slots, an overflowing bucket: by the wave, when the scan gets there
+            dead = !ok | (!ovf & (cnt == 0));                // (no such k-mer in the reference after all: never an event)
+            const u32 en = m0 ? bkv.x : m1 ? bkv.y : m2 ? bkv.z : bkv.w;
+            pos = simple ? (int)(en & (u32)lowmask(I.posbits)) : 0;
+        } else {
+            simple = !(slot & AQ_COMPLEX);
+            // (a lane without a simple candidate must not wander: slot 0 may hold BK_EMPTY, whose position bits point
+            // far beyond the text)
+            pos = simple ? (int)(I.bk[simple ? slot : 0u] & (u32)lowmask(I.posbits)) : 0;
         }
-        const bool simple = !(slot & AQ_COMPLEX);
-        // (a lane without a simple candidate must not wander: slot 0 may hold BK_EMPTY, whose position bits point
-        // far beyond the text)
-        const int pos = simple ? (int)(I.bk[simple ? slot : 0u] & (u32)lowmask(I.posbits)) : 0;
         // 32 symbols of both texts from pos / qp on, as one 64-bit word each (funnel of two words, no branch)
         const u32 wr = (u32)pos >> 5, wq = (u32)qp >> 5;
         const int sr = (pos & 31) * 2, sq = (qp & 31) * 2;
@@ -566,7 +577,7 @@ struct DevWave {
         // another k-mer in the bucket, about as many per pair as there are true anchors: it leaves the queue here, all
         // of a batch in one stable compaction (lane permute, no LDS memory), instead of costing the sequential scan a
         // step each.  (The lanes behind the last kept candidate receive leftovers; their position says AQ_NONE.)
-        const bool kept = live & !(simple & !lng & (al0 < P.mal));
+        const bool kept = live & !dead & !(simple & !lng & (al0 < P.mal));
         const u64 keep = wballot(kept);
         if (keep != lowmask(q_cnt)) {
             const int to = 4 * (kept ? (int)__builtin_amdgcn_mbcnt_hi((u32)(keep >> 32), __builtin_amdgcn_mbcnt_lo((u32)keep, 0u)) : 63);

@@ -185,16 +185,46 @@ def test_full_size_properties_1000_genomes():
             assert tuple(res[r, q]) == O.oracle_pair(seqs[r], seqs[q]), (r, q)
 
 
-def test_long_genomes_config4_shape():
+def test_long_genomes_config4_shape(monkeypatch):
     """BASELINE configs[3] in miniature: Mbp-scale genomes with --mal 15 --msl 9 --reg 60 (24-bit text
-    positions, 2^20+ bucket directory, several hundred extension chunks per match)."""
+    positions, 2^21 bucket directory, several hundred extension chunks per match).  At this size the tags are 9
+    bits wide -- no tag byte holds them, so there are no tag words and the probe form falls back to the rounds of the
+    first kernel; dense rows (from 8 rows on) take their candidates from the presence matrix instead: the pair's
+    bitmap, the candidate's bucket read whole.  Six genomes by rounds and, forced, by bitmaps; then 24 genomes of
+    300 kbp (10-bit tags) both ways, timed."""
+    import time
     _, seqs = SG.make_set(6, 3, lmin=900_000, lmax=1_100_000, fam=3, dmin=0.005, dmax=0.08)
     prm = dict(mal=15, msl=9, reg=60)
-    got = gpu_all2all(seqs, prm)
     want = O.oracle_all2all(seqs, prm, threads=16)
+    eng = L.Engine(prm)
+    eng.set_genomes(seqs)
+    lay = eng.layout()
+    assert lay["tag_words"] == 0 and lay["bucket_table"] == 1 and lay["join_lists"] == 0
+    got = eng.all2all()
+    assert eng.layout()["bitmap_launches"] == 0
     bad = np.argwhere((got != want).any(axis=2))
     assert len(bad) == 0, (bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
     assert got[0, 1, 0] > 800_000          # related genomes really align over most of their length
+    monkeypatch.setenv("LZANI_PM_MIN_ROWS", "1")
+    got = eng.all2all()
+    assert eng.layout()["bitmap_launches"] == 1
+    monkeypatch.delenv("LZANI_PM_MIN_ROWS")
+    eng.close()
+    assert np.array_equal(got, want)
+    _, seqs = SG.make_set(24, 5, lmin=280_000, lmax=320_000, fam=4, dmin=0.005, dmax=0.08)
+    want = O.oracle_all2all(seqs, prm, threads=16)
+    eng = L.Engine(prm)
+    eng.set_genomes(seqs)
+    assert eng.layout()["tag_words"] == 0
+    got = eng.all2all()                       # (also makes the k-mer words: not in either timing below)
+    assert eng.layout()["bitmap_launches"] == 1 and np.array_equal(got, want)
+    t = time.perf_counter(); eng.all2all(); t_pm = time.perf_counter() - t
+    monkeypatch.setenv("LZANI_PM", "0")
+    t = time.perf_counter(); got0 = eng.all2all(); t_rounds = time.perf_counter() - t
+    assert eng.layout()["bitmap_launches"] == 0
+    eng.close()
+    assert np.array_equal(got0, want)
+    print(f"24 x 300 kbp, mal 15: {t_pm * 1e3:.0f} ms with candidate bitmaps, {t_rounds * 1e3:.0f} ms by rounds")
 
 
 def test_filtered_heavy_tailed_rows_config5_shape():
