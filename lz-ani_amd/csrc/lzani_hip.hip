@@ -107,6 +107,8 @@ struct lzani_ctx {
     size_t pm_bytes = 0;
     u32* d_pm_cbits = nullptr;    // candidate bitmaps of a batch's pairs
     size_t pm_cbits_bytes = 0;
+    u32* d_pm_pidx = nullptr;     // rows with query lists: pair of (query, slot of the group), query flags + list + count behind it
+    size_t pm_pidx_bytes = 0;
     int pm_launches = 0;          // pair-kernel launches of the last run fed by candidate bitmaps
     bool pm_attr_set = false;
 
@@ -164,8 +166,8 @@ void free_genomes(lzani_ctx* c)
 }
 void free_pm(lzani_ctx* c)
 {
-    hipFree(c->d_pm); hipFree(c->d_pm_cbits);
-    c->d_pm = c->d_pm_cbits = nullptr; c->pm_bytes = c->pm_cbits_bytes = 0;
+    hipFree(c->d_pm); hipFree(c->d_pm_cbits); hipFree(c->d_pm_pidx);
+    c->d_pm = c->d_pm_cbits = c->d_pm_pidx = nullptr; c->pm_bytes = c->pm_cbits_bytes = c->pm_pidx_bytes = 0;
 }
 void free_slabs(lzani_ctx* c)
 {
@@ -489,9 +491,21 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             return fail(c, LZANI_ERR_ARG, "lzani_run_rows: dense row must have n-1 queries");
     }
     if (row_off[0] != 0) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: row_off[0] must be 0");
-    if (query_ids)
-        for (u64 e = 0; e < n_pairs; ++e)
-            if (query_ids[e] >= c->n) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: query id out of range");
+    // (query lists: the same pass tells whether a row names a query twice and how many queries a group of PM_GROUP
+    // consecutive rows involves -- what the candidate stage below goes by)
+    bool lists_dup = false;
+    u64 lists_involved = 0;
+    if (query_ids) {
+        std::vector<u32> in_row(c->n, 0xFFFFFFFFu), in_group(c->n, 0xFFFFFFFFu);
+        for (u32 k = 0; k < n_rows; ++k)
+            for (u64 e = row_off[k]; e < row_off[k + 1]; ++e) {
+                const u32 q = query_ids[e];
+                if (q >= c->n) return fail(c, LZANI_ERR_ARG, "lzani_run_rows: query id out of range");
+                lists_dup |= in_row[q] == k;
+                in_row[q] = k;
+                if (in_group[q] != k / PM_GROUP) { in_group[q] = k / PM_GROUP; ++lists_involved; }
+            }
+    }
     if (n_pairs == 0) return LZANI_OK;
 
     HIPCHK(c, hipSetDevice(c->dev));
@@ -507,7 +521,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     u32 pm_tiles = 0, pm_group = PM_GROUP;
     const int pm_bits = std::min(c->geo.kb, 30);             // exact up to mal 15: the mixer is a bijection on the key bits
     u32 want_rows = n_rows;
-    size_t pm_per_row = 0;
+    u64 pm_cap_pairs = 0;                                    // pairs whose bitmaps a batch may hold
     {
         const char* e = getenv("LZANI_PM");
         const char* mn = getenv("LZANI_PM_MIN_ROWS");
@@ -516,31 +530,46 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         // first kernel: genomes whose tags do not fit a tag byte -- 260 kbp to 2 Mbp at mal 15, viral sizes at mal 13+.
         // Below, the matrix -- 16 GB to clear at 30 key bits -- costs more than it saves.)
         const u32 min_rows = mn ? (u32)std::max(1, atoi(mn)) : c->tw_stride ? 32u : 8u;
-        pm = !rs && !query_ids && c->d_kmL && c->bk_stride && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 30 &&
+        // Query lists qualify when they are dense where they are: a query that occurs in a group of rows should meet a
+        // good part of it (one matrix row read serves all its pairs of the group) -- the row x column blocks of a tiled
+        // all2all do, the few relatives a kmer-db filter leaves per row do not.  No query twice in a row (one bitmap each).
+        const bool lists_ok = !query_ids || (!lists_dup && n_pairs >= 48 * lists_involved);
+        pm = !rs && lists_ok && c->d_kmL && c->bk_stride && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 30 &&
              c->n >= 2 && n_rows >= min_rows && !(e && *e == '0');
         if (pm) {
             int Lmax = 0;
+            u64 max_row = 0;
             for (u32 g = 0; g < c->n; ++g) Lmax = std::max(Lmax, c->L[g]);
+            for (u32 k = 0; k < n_rows; ++k) max_row = std::max<u64>(max_row, row_off[k + 1] - row_off[k]);
             pm_tiles = (u32)(((u64)Lmax + c->P.mrd + 320 + PM_TILE - 1) / PM_TILE);
             cb_words = (u64)pm_tiles * PM_TILE_WORDS;
             pm_group = pm_bits <= 24 ? (u32)PM_GROUP : 128u;                      // 64-byte rows up to 2^24 of them, 16-byte rows beyond (16 GB at 2^30)
             const size_t m_bytes = ((size_t)1 << pm_bits) * (pm_group / 8);
-            pm_per_row = (size_t)(c->n - 1) * cb_words * 4;
+            const size_t x_bytes = query_ids ? ((size_t)c->n * pm_group + 2 * (size_t)c->n + 64) * 4 : 0;   // pair table, query flags, list, count
+            const size_t per_pair = (size_t)cb_words * 4;
+            const double avg_row = (double)n_pairs / n_rows;
             const size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride) + (c->sort_build ? (size_t)16 * c->Tmax + 16 : 0);
             size_t free_b = 0, total_b = 0;
             HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-            const size_t pool = free_b + (size_t)c->slots * per_slot + c->pm_cbits_bytes + c->pm_bytes;   // what this run may lay out anew
+            const size_t pool = free_b + (size_t)c->slots * per_slot + c->pm_cbits_bytes + c->pm_bytes + c->pm_pidx_bytes;   // what this run may lay out anew
             const size_t cap = mb ? (size_t)strtoull(mb, nullptr, 10) : std::min((size_t)64 << 30, total_b / 4);
-            u64 fit = (size_t)(pool * 0.85) > m_bytes ? ((size_t)(pool * 0.85) - m_bytes) / (per_slot + pm_per_row) : 0;
-            fit = std::min<u64>(fit, cap / pm_per_row);
-            fit = std::min<u64>(fit, 0xFFFFFFF0ull / (u64)(c->n - 1));             // pair indexes of a batch are 32 bits
-            if (fit < 8) pm = false;                          // (a genome set this large: the probe / join form, batch by batch)
+            const double room = pool * 0.85 - (double)m_bytes - (double)x_bytes;
+            u64 fit = room > 0 ? (u64)(room / ((double)per_slot + avg_row * (double)per_pair)) : 0;     // rows: a slab + its pairs' bitmaps each
+            fit = std::min<u64>(fit, std::min<u32>(n_rows, c->max_slots));
+            pm_cap_pairs = std::min<u64>((u64)(cap / per_pair), 0xFFFFFFF0ull);                          // pair indexes of a batch are 32 bits
+            pm_cap_pairs = std::min<u64>(pm_cap_pairs, (u64)((double)fit * avg_row) + max_row);
+            if (fit < std::min<u32>(8, n_rows) || pm_cap_pairs < max_row) pm = false;    // (a genome set this large: the probe / join form, batch by batch)
             else {
-                want_rows = (u32)std::min<u64>(n_rows, fit);
+                want_rows = (u32)fit;
                 if (c->pm_bytes < m_bytes) {
                     hipFree(c->d_pm); c->d_pm = nullptr; c->pm_bytes = 0;
                     HIPCHK(c, hipMalloc(&c->d_pm, m_bytes));
                     c->pm_bytes = m_bytes;
+                }
+                if (c->pm_pidx_bytes < x_bytes) {
+                    hipFree(c->d_pm_pidx); c->d_pm_pidx = nullptr; c->pm_pidx_bytes = 0;
+                    HIPCHK(c, hipMalloc(&c->d_pm_pidx, x_bytes));
+                    c->pm_pidx_bytes = x_bytes;
                 }
             }
         }
@@ -549,22 +578,39 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     if (use_join) { rc = ensure_join(c); if (rc) return rc; }          // (before the slabs are sized: they take 60 % of what is left)
     rc = ensure_slabs(c, want_rows);
     if (rc) return rc;
-    u32 bs = c->slots;                                       // rows per batch
-    if (pm) {
-        bs = std::min(bs, want_rows);
-        if (bs < n_rows && bs > pm_group) bs -= bs % pm_group;           // several batches: whole groups
-        const size_t need = (size_t)std::min(bs, n_rows) * pm_per_row;
-        if (c->pm_cbits_bytes < need) {
-            hipFree(c->d_pm_cbits); c->d_pm_cbits = nullptr; c->pm_cbits_bytes = 0;
-            HIPCHK(c, hipMalloc(&c->d_pm_cbits, need));
-            c->pm_cbits_bytes = need;
+    // Batches: as many consecutive rows as there are index slabs -- and, with candidate bitmaps, as their pairs' bitmaps
+    // may take.
+    std::vector<u32> bstart(1, 0);
+    {
+        u32 rows = 0, rows_cap = c->slots;
+        u64 pairs = 0, most = 0;
+        if (pm && !query_ids) {                              // dense rows: whole groups of references, if there are several batches
+            u64 r = std::min<u64>(rows_cap, pm_cap_pairs / (u64)(c->n - 1));
+            if (r < n_rows && r > pm_group) r -= r % pm_group;
+            rows_cap = (u32)std::max<u64>(r, 1);
+        }
+        for (u32 k = 0; k < n_rows; ++k) {
+            const u64 len = row_off[k + 1] - row_off[k];
+            if (rows && (rows == rows_cap || (pm && pairs + len > pm_cap_pairs))) { bstart.push_back(k); most = std::max(most, pairs); rows = 0; pairs = 0; }
+            ++rows; pairs += len;
+        }
+        bstart.push_back(n_rows);
+        most = std::max(most, pairs);
+        if (pm) {
+            const size_t need = (size_t)most * cb_words * 4;
+            if (c->pm_cbits_bytes < need) {
+                hipFree(c->d_pm_cbits); c->d_pm_cbits = nullptr; c->pm_cbits_bytes = 0;
+                HIPCHK(c, hipMalloc(&c->d_pm_cbits, need));
+                c->pm_cbits_bytes = need;
+            }
         }
     }
+    const u32 bs = c->slots;
 
     // Batches of `bs` rows (one index slab per row).  Everything the batches need from the host -- row tables
     // and the per-XCD work queues of every batch -- is prepared and uploaded before the first launch, so the
     // batches follow each other on the stream without a host round trip in between.
-    const u32 n_batches = (n_rows + bs - 1) / bs;
+    const u32 n_batches = (u32)bstart.size() - 1;
     c->batches_last_run = n_batches;
     std::vector<u32> qorder(n_rows);
     std::vector<u64> qcum((size_t)n_rows + n_batches);
@@ -572,8 +618,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     {
         std::vector<u32> by_size;
         std::vector<u32> queue[NQUEUES];
-        for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += bs) {
-            const u32 rows = std::min(bs, n_rows - k0);
+        for (u32 b = 0; b < n_batches; ++b) {
+            const u32 k0 = bstart[b], rows = bstart[b + 1] - k0;
             auto rlen = [&](u32 k) { return row_off[k0 + k + 1] - row_off[k0 + k]; };
             // rows -> queues: longest row first onto the least loaded queue (equal rows: round robin)
             by_size.resize(rows);
@@ -637,8 +683,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         HIPCHK(c, d_cbits.alloc((size_t)max_blocks * 4 * cbits_stride));
     }
 
-    for (u32 b = 0, k0 = 0; k0 < n_rows; ++b, k0 += bs) {
-        const u32 rows = std::min(bs, n_rows - k0);
+    for (u32 b = 0; b < n_batches; ++b) {
+        const u32 k0 = bstart[b], rows = bstart[b + 1] - k0;
         const u64 e0 = row_off[k0], e1 = row_off[k0 + rows];
         hipEvent_t* ev = c->events.data() + (size_t)EV * b;
         TRACE("batch %u rows [%u,%u) pairs [%llu,%llu) slots=%u pm=%d", b, k0, k0 + rows, (unsigned long long)e0, (unsigned long long)e1, bs, (int)pm);
@@ -659,6 +705,14 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 pg.M = c->d_pm; pg.rw = ((pg.rows + 127) / 128) * 4; pg.mmask = (u32)lowmask(pm_bits);
                 pg.mal = c->P.mal; pg.mrd = c->P.mrd;
                 pg.cbits = c->d_pm_cbits; pg.cb_words = cb_words; pg.e0 = e0; pg.n = c->n; pg.q0 = 0;
+                pg.query_ids = d_q.p; pg.pidx = nullptr; pg.qflag = pg.qlist = pg.qcount = nullptr;
+                if (query_ids) {                            // the lists of the group's rows -> pair table + the queries involved
+                    const size_t tab = (size_t)c->n * 32 * pg.rw;
+                    pg.pidx = c->d_pm_pidx; pg.qflag = c->d_pm_pidx + (size_t)c->n * pm_group; pg.qlist = pg.qflag + c->n; pg.qcount = pg.qlist + c->n;
+                    HIPCHK(c, hipMemsetAsync(pg.pidx, 0xFF, tab * 4, c->stream));
+                    HIPCHK(c, hipMemsetAsync(pg.qflag, 0, ((size_t)2 * c->n + 1) * 4, c->stream));
+                    hipLaunchKernelGGL(k_pm_pairs, dim3(pg.rows), dim3(256), 0, c->stream, pg);
+                }
                 HIPCHK(c, hipMemsetAsync(c->d_pm, 0, ((size_t)1 << pm_bits) * pg.rw * 4, c->stream));
                 hipLaunchKernelGGL(k_pm_build, dim3((u32)std::min<u64>(((u64)c->Tmax + 255) / 256, 64), pg.rows), dim3(256), 0, c->stream, pg, c->Tmax);
                 const u32 rp = 32 * pg.rw;

@@ -38,7 +38,17 @@ struct PmArgs {
     u64 cb_words;
     u64 e0;                   // absolute pair offset of the batch's first pair
     u32 n;                    // genomes (a dense row holds the n - 1 others, ascending)
-    u32 q0;                   // k_pm_cand: first query of this launch (gridDim.y is limited)
+    u32 q0;                   // k_pm_cand: first query (dense rows) / first list entry (query lists) of this launch (gridDim.y is limited)
+    // rows with query lists (the filtered form of lz_matcher.cpp:234-250, or the row x column blocks a host cuts a dense
+    // all2all into): query_ids = the lists, CSR with row_off; k_pm_pairs turns them into
+    //   pidx[q * RP + s]   the pair of query q in the row of slot s of the group (batch-relative), ~0 = none
+    //   qlist / qcount     the queries that occur in the group at all -- only these get candidate bitmaps
+    // nullptr = dense rows.
+    const u32* query_ids;
+    u32* pidx;
+    u32* qflag;
+    u32* qlist;
+    u32* qcount;
 };
 
 // One thread per text position of the group's references: the slot's bit in the row of the position's mal-mer.
@@ -55,6 +65,18 @@ __global__ void __launch_bounds__(256) k_pm_build(PmArgs a, int Tmax)
     }
 }
 
+// Rows with query lists: one block per slot of the group walks the row's list (no query twice in a row: the host checks).
+__global__ void __launch_bounds__(256) k_pm_pairs(PmArgs a)
+{
+    const u32 s = blockIdx.x, RP = 32u * a.rw;
+    const u64 b = a.row_off[a.slot0 + s], e = a.row_off[a.slot0 + s + 1];
+    for (u64 k = b + threadIdx.x; k < e; k += blockDim.x) {
+        const u32 q = a.query_ids[k];
+        a.pidx[(u64)q * RP + s] = (u32)(k - a.e0);
+        if (atomicExch(&a.qflag[q], 1u) == 0u) a.qlist[atomicAdd(a.qcount, 1u)] = q;
+    }
+}
+
 // LDS tile of k_pm_cand: word c (32 positions) of slot s at c * (RP + 1) + s, RP = 32 * rw slots: the scatter of a
 // wave (64 consecutive positions = two words c, any slots) and the gather of the write-out (one slot, 32 words c)
 // both fall on distinct banks.
@@ -66,14 +88,19 @@ __global__ void __launch_bounds__(256) k_pm_cand(PmArgs a)
     extern __shared__ u32 s_tile[];                    // 32 x (RP + 1) words, then RP pair indexes
     const u32 RP = 128u * RW4, rp1 = RP + 1;
     u32* const s_pair = s_tile + PM_TILE_WORDS * rp1;  // per slot: the pair's index in the batch, or ~0 (no pair)
-    const u32 q = a.q0 + blockIdx.y;
+    u32 q = a.q0 + blockIdx.y;
+    if (a.qlist) {                                     // (block-uniform) query lists: the queries that occur in this group
+        if (q >= *a.qcount) return;
+        q = a.qlist[q];
+    }
     const int D = a.G.L[q] + a.mrd;
     const int p0 = (int)blockIdx.x * PM_TILE;
     if (p0 >= D + 320) return;                         // (block-uniform) the pair kernel reads five words beyond its scan position at most
     for (u32 k = threadIdx.x; k < PM_TILE_WORDS * rp1; k += 256) s_tile[k] = 0;
     for (u32 s = threadIdx.x; s < RP; s += 256) {
         u32 pe = 0xFFFFFFFFu;
-        if (s < a.rows) {
+        if (a.pidx) pe = a.pidx[(u64)q * RP + s];
+        else if (s < a.rows) {
             const u32 r = a.ref_ids[a.slot0 + s];
             if (r != q) pe = (u32)(a.row_off[a.slot0 + s] - a.e0) + q - (q > r ? 1u : 0u);
         }

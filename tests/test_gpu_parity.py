@@ -683,6 +683,61 @@ def test_presence_matrix_candidates(monkeypatch):
     assert np.array_equal(got, want)
 
 
+def test_presence_matrix_with_query_lists():
+    """Candidate bitmaps for rows with query LISTS that are dense where they are: the row x column blocks a host cuts
+    a dense all2all into so that it can emit finished rows while the GPU works on the next block (lz-ani does) --
+    block A = rows A against the queries from A on, plus the rows behind A against the queries of A.  Every pair of
+    the matrix comes out exactly once over the blocks and equals the oracle; sparse lists (a kmer-db filter's) and
+    lists that name a query twice keep the probe form."""
+    _, seqs = SG.make_set(150, 31, lmin=17000, lmax=20000, fam=10)
+    n = len(seqs)
+    want = O.oracle_all2all(seqs, None, threads=16)
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    got = np.zeros_like(want)
+    seen = np.zeros((n, n), dtype=np.int32)
+    bk = 40
+    for a0 in range(0, n, bk):
+        a1 = min(n, a0 + bk)
+        rows, lists = [], []
+        for r in range(a0, a1):
+            rows.append(r); lists.append([q for q in range(a0, n) if q != r])
+        for r in range(a1, n):
+            rows.append(r); lists.append(list(range(a0, a1)))
+        keep = [k for k in range(len(rows)) if lists[k]]
+        rows = [rows[k] for k in keep]; lists = [lists[k] for k in keep]
+        off = np.zeros(len(rows) + 1, np.uint64)
+        off[1:] = np.cumsum([len(x) for x in lists])
+        out = eng.run_rows(np.array(rows, np.uint32), off, np.array([q for x in lists for q in x], np.uint32)).reshape(-1, 3)
+        lay = eng.layout()
+        assert lay["bitmap_launches"] == lay["batches_last_run"] >= 1 if len(rows) >= 32 else True, (a0, lay)
+        e = 0
+        for r, x in zip(rows, lists):
+            for q in x:
+                got[r, q] = out[e]; seen[r, q] += 1; e += 1
+    assert (seen + np.eye(n, dtype=np.int32) == 1).all()
+    assert np.array_equal(got, want)
+    # sparse lists: three relatives per row -> the probe form
+    rows = np.arange(n, dtype=np.uint32)
+    lists = [[(r + d) % n for d in (1, 2, 3)] for r in range(n)]
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(3)
+    out = eng.run_rows(rows, off, np.array([q for x in lists for q in x], np.uint32)).reshape(n, 3, 3)
+    assert eng.layout()["bitmap_launches"] == 0
+    assert all(np.array_equal(out[r, k], want[r, lists[r][k]]) for r in range(n) for k in range(3))
+    # a query twice in a row: one bitmap per (row, query) would not do -> the probe form as well
+    lists = [[q for q in range(n) if q != r] + [(r + 1) % n] for r in range(64)]
+    off = np.zeros(65, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    out = eng.run_rows(np.arange(64, dtype=np.uint32), off, np.array([q for x in lists for q in x], np.uint32)).reshape(-1, 3)
+    assert eng.layout()["bitmap_launches"] == 0
+    eng.close()
+    e = 0
+    for r, x in enumerate(lists):
+        for q in x:
+            assert np.array_equal(out[e], want[r, q]), (r, q)
+            e += 1
+
+
 def test_block_kernel_with_lds_filter(monkeypatch):
     """Rows of >= 128 pairs run by blocks of 16 waves that keep the reference's presence filter in LDS (k_pairs_blk,
     with the null chain where the parameters are the defaults): whole matrices against the oracle -- N-free and with N,
