@@ -282,74 +282,106 @@ inline void format_row(const std::vector<Genome>& g, const std::vector<uint32_t>
     }
 }
 
-inline bool store_results(const std::vector<Genome>& g, const PairTable& T, const EmitParams& ep)
-{
-    std::string fn_ids, fn_anis;
-    if (!ep.single_txt) {
-        fn_anis = ep.out_name;
-        fn_ids = ep.ids_name;
-        if (fn_ids.empty()) {                             // <stem>.ids<ext> (lz_matcher.cpp:295-302)
-            auto p = fn_anis.rfind('.');
-            fn_ids = p == std::string::npos ? fn_anis + ".ids" : fn_anis.substr(0, p) + ".ids" + fn_anis.substr(p);
+// The result files, written front to back: open() puts down the ids file and the header line, emit_rows(a0, a1)
+// the text of the reference rows [a0, a1) -- which needs every pair {a, b > a} of those rows in both directions, no
+// more -- and close() finishes.  A host that computes the all2all block by block (lz-ani's tiled matching) emits the
+// rows of a block while the GPU works on the next one; store_results below is the same thing in one go.
+class ResultWriter {
+public:
+    bool open(const std::vector<Genome>& g, const EmitParams& ep_)
+    {
+        ep = ep_;
+        std::string fn_ids, fn_anis;
+        if (!ep.single_txt) {
+            fn_anis = ep.out_name;
+            fn_ids = ep.ids_name;
+            if (fn_ids.empty()) {                             // <stem>.ids<ext> (lz_matcher.cpp:295-302)
+                auto p = fn_anis.rfind('.');
+                fn_ids = p == std::string::npos ? fn_anis + ".ids" : fn_anis.substr(0, p) + ".ids" + fn_anis.substr(p);
+            }
+        } else fn_ids = ep.out_name;
+        ofs.open(fn_ids, std::ios::binary);
+        if (!ofs.is_open()) { std::cerr << "Cannot open output file: " << fn_ids << std::endl; return false; }
+        // reported length: separators between the contigs of a multi-part item are not counted (lz_matcher.cpp:430-431)
+        len.resize(g.size());
+        for (size_t i = 0; i < g.size(); ++i) len[i] = (uint32_t)g[i].codes.size() - (g[i].no_parts - 1) * (uint32_t)ep.mrd;
+        if (ep.single_txt) {
+            ofs << ep.params_dump;
+            ofs << "[no_input_sequences]\n" << g.size() << "\n[input_sequences]\n";
+            for (size_t i = 0; i < g.size(); ++i) ofs << g[i].name << " " << len[i] << " " << g[i].no_parts << "\n";
+            ofs << "[lz_similarities]\n";
+        } else {
+            ofs << "id\tseq_len\tno_parts\n";
+            for (size_t i = 0; i < g.size(); ++i) ofs << g[i].name << "\t" << len[i] << "\t" << g[i].no_parts << "\n";
+            ofs.close();
+            ofs.open(fn_anis, std::ios::binary);
+            if (!ofs.is_open()) { std::cerr << "Cannot open output file: " << fn_anis << std::endl; return false; }
+            bool first = true;
+            for (Comp c : ep.comps) {
+                if (!first) ofs << "\t";
+                first = false;
+                for (auto& kv : comp_names()) if (kv.second == c) ofs << kv.first;
+            }
+            ofs << "\n";
         }
-    } else fn_ids = ep.out_name;
-
-    std::ofstream ofs(fn_ids, std::ios::binary);
-    if (!ofs.is_open()) { std::cerr << "Cannot open output file: " << fn_ids << std::endl; return false; }
-    // reported length: separators between the contigs of a multi-part item are not counted (lz_matcher.cpp:430-431)
-    std::vector<uint32_t> len(g.size());
-    for (size_t i = 0; i < g.size(); ++i) len[i] = (uint32_t)g[i].codes.size() - (g[i].no_parts - 1) * (uint32_t)ep.mrd;
-    if (ep.single_txt) {
-        ofs << ep.params_dump;
-        ofs << "[no_input_sequences]\n" << g.size() << "\n[input_sequences]\n";
-        for (size_t i = 0; i < g.size(); ++i) ofs << g[i].name << " " << len[i] << " " << g[i].no_parts << "\n";
-        ofs << "[lz_similarities]\n";
-    } else {
-        ofs << "id\tseq_len\tno_parts\n";
-        for (size_t i = 0; i < g.size(); ++i) ofs << g[i].name << "\t" << len[i] << "\t" << g[i].no_parts << "\n";
-        ofs.close();
-        ofs.open(fn_anis, std::ios::binary);
-        if (!ofs.is_open()) { std::cerr << "Cannot open output file: " << fn_anis << std::endl; return false; }
-        bool first = true;
-        for (Comp c : ep.comps) {
-            if (!first) ofs << "\t";
-            first = false;
-            for (auto& kv : comp_names()) if (kv.second == c) ofs << kv.first;
-        }
-        ofs << "\n";
+        cuts = make_cuts(ep);
+        return true;
     }
 
     // Formatter threads fill the row strings of one block while the writer thread puts the previous block on disk,
     // in row order; two blocks of a few rows per thread are all that is ever held (a 10,000-genome row is ~1.8 MB of
     // text, the whole file 9 GB).
-    const std::vector<Cut> cuts = make_cuts(ep);
-    const size_t n = T.n;
-    const uint32_t nt = std::max<uint32_t>(1, ep.threads);
-    const size_t block = std::max<size_t>(8, 4 * (size_t)nt);
-    std::vector<std::string> text[2];
-    text[0].resize(std::min(n, block)); text[1].resize(std::min(n, block));
-    std::thread writer;
-    for (size_t base = 0, k2 = 0; base < n; base += block, k2 ^= 1) {
-        const size_t cnt = std::min(block, n - base);
-        std::vector<std::string>& buf = text[k2];
-        std::atomic<size_t> next{0};
-        auto worker = [&]() {
-            for (;;) {
-                size_t k = next.fetch_add(1);
-                if (k >= cnt) break;
-                buf[k].clear();
-                format_row(g, len, T, ep, cuts, (uint32_t)(base + k), buf[k]);
-            }
-        };
-        std::vector<std::thread> th;
-        for (uint32_t t = 1; t < std::min<uint32_t>(nt, (uint32_t)cnt); ++t) th.emplace_back(worker);
-        worker();
-        for (auto& t : th) t.join();
-        if (writer.joinable()) writer.join();                  // the block before this one is on disk: its buffer is free again
-        writer = std::thread([&ofs, &buf, cnt]() { for (size_t k = 0; k < cnt; ++k) ofs.write(buf[k].data(), (std::streamsize)buf[k].size()); });
+    void emit_rows(const std::vector<Genome>& g, const PairTable& T, size_t a0, size_t a1)
+    {
+        const uint32_t nt = std::max<uint32_t>(1, ep.threads);
+        const size_t block = std::max<size_t>(8, 4 * (size_t)nt);
+        text[0].resize(block); text[1].resize(block);
+        for (size_t base = a0; base < a1; base += block, cur ^= 1) {
+            const size_t cnt = std::min(block, a1 - base);
+            std::vector<std::string>& buf = text[cur];
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (;;) {
+                    size_t k = next.fetch_add(1);
+                    if (k >= cnt) break;
+                    buf[k].clear();
+                    format_row(g, len, T, ep, cuts, (uint32_t)(base + k), buf[k]);
+                }
+            };
+            std::vector<std::thread> th;
+            for (uint32_t t = 1; t < std::min<uint32_t>(nt, (uint32_t)cnt); ++t) th.emplace_back(worker);
+            worker();
+            for (auto& t : th) t.join();
+            if (writer.joinable()) writer.join();              // the block before this one is on disk: its buffer is free again
+            std::ofstream* o = &ofs;
+            writer = std::thread([o, &buf, cnt]() { for (size_t k = 0; k < cnt; ++k) o->write(buf[k].data(), (std::streamsize)buf[k].size()); });
+        }
     }
-    if (writer.joinable()) writer.join();
-    ofs.close();
+
+    bool close()
+    {
+        if (writer.joinable()) writer.join();
+        ofs.close();
+        return !ofs.fail();
+    }
+    ~ResultWriter() { if (writer.joinable()) writer.join(); }
+
+private:
+    EmitParams ep;
+    std::ofstream ofs;
+    std::vector<uint32_t> len;
+    std::vector<Cut> cuts;
+    std::vector<std::string> text[2];
+    int cur = 0;
+    std::thread writer;
+};
+
+inline bool store_results(const std::vector<Genome>& g, const PairTable& T, const EmitParams& ep)
+{
+    ResultWriter w;
+    if (!w.open(g, ep)) return false;
+    w.emit_rows(g, T, 0, T.n);
+    w.close();
     return true;
 }
 

@@ -10,6 +10,8 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cstdlib>
 #include <fstream>
 #include <iterator>
@@ -327,8 +329,7 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, Filter& flt, P
         lzani_group* grp = nullptr;
         int rc = E.group_create(&P.lz, (uint32_t)devs.size(), devs.data(), &grp);
         if (rc != LZANI_OK) {
-            cerr << "LZ matching failed: lzani_group_create failed with code " << rc
-                 << (rc == LZANI_ERR_PARAMS ? " (LZ parameters outside the supported envelope)" : rc == LZANI_ERR_DEVICE ? " (no such GPU, or RCCL could not connect the GPUs)" : "") << endl;
+            cerr << "LZ matching failed: lzani_group_create failed with code " << rc << ": " << E.group_last_error(nullptr) << endl;
             return false;
         }
         rc = E.group_set_genomes(grp, n, ptr.data(), len.data());
@@ -404,6 +405,109 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, Filter& flt, P
     return true;
 }
 
+// Dense all2all, tiled: the matrix goes to the engine in row x column blocks -- block A = the rows of A against the
+// queries from A on, plus the rows behind A against the queries of A -- so that after block A every pair {a in A, b > a}
+// is there in both directions, which is all the text of the reference rows A needs (store_results, lz_matcher.cpp:
+// 371-567, walks the pairs the same way, after ALL of do_matching): an emitter thread formats and writes the rows of A
+// while the GPUs work on the next block.  Every directed pair is still computed exactly once; the file is byte for
+// byte the one the untiled run writes.
+static bool do_matching_tiled(const Engine& E, const vector<Genome>& g, PairTable& T, const EmitParams& ep, uint32_t tile)
+{
+    const uint32_t n = (uint32_t)g.size();
+    if (P.verbosity >= 1) cerr << "All2all sparse" << endl;
+    T.init_dense(n);
+    vector<const uint8_t*> ptr(n);
+    vector<uint32_t> len(n);
+    for (uint32_t i = 0; i < n; ++i) { ptr[i] = g[i].codes.data(); len[i] = (uint32_t)g[i].codes.size(); }
+    const int ng = max(1, min<int>(P.gpus, (int)max<uint32_t>(n, 1)));
+    vector<int> devs(ng);
+    for (int d = 0; d < ng; ++d) devs[d] = P.device + d;
+    if (const char* e = getenv("LZANI_DEVICE_LIST")) {           // rehearsals: e.g. "0,0,0" runs three shards on one GPU
+        devs.clear();
+        for (const auto& x : split(e, ',')) devs.push_back(atoi(x.c_str()));
+        if (devs.empty()) devs.push_back(P.device);
+    }
+    lzani_group* grp = nullptr;
+    int rc = E.group_create(&P.lz, (uint32_t)devs.size(), devs.data(), &grp);
+    if (rc != LZANI_OK) {
+        cerr << "LZ matching failed: lzani_group_create failed with code " << rc << ": " << E.group_last_error(nullptr) << endl;
+        return false;
+    }
+    rc = E.group_set_genomes(grp, n, ptr.data(), len.data());
+    if (rc != LZANI_OK) { cerr << "LZ matching failed: " << E.group_last_error(grp) << endl; E.group_destroy(grp); return false; }
+
+    ResultWriter W;
+    if (!W.open(g, ep)) { E.group_destroy(grp); return false; }
+    // emitter: the row blocks in order, as they complete
+    mutex mtx;
+    condition_variable cv;
+    deque<pair<uint32_t, uint32_t>> ready;
+    bool done = false;
+    thread emitter([&]() {
+        for (;;) {
+            pair<uint32_t, uint32_t> blk;
+            {
+                unique_lock<mutex> lk(mtx);
+                cv.wait(lk, [&]() { return done || !ready.empty(); });
+                if (ready.empty()) return;
+                blk = ready.front(); ready.pop_front();
+            }
+            W.emit_rows(g, T, blk.first, blk.second);
+        }
+    });
+    vector<double> t_index(devs.size(), 0), t_pairs(devs.size(), 0), t_cand(devs.size(), 0);
+    vector<uint64_t> n_pairs(devs.size(), 0);
+    double t_gather = 0;
+    vector<uint32_t> rows, q;
+    vector<uint64_t> off;
+    vector<lzani_result> out;
+    bool ok = true;
+    for (uint32_t a0 = 0; a0 < n && ok; a0 += tile) {
+        const uint32_t a1 = min(n, a0 + tile);
+        rows.clear(); q.clear(); off.assign(1, 0);
+        for (uint32_t r = a0; r < n; ++r) {
+            const size_t before = q.size();
+            if (r < a1) { for (uint32_t x = a0; x < n; ++x) if (x != r) q.push_back(x); }
+            else for (uint32_t x = a0; x < a1; ++x) q.push_back(x);
+            if (q.size() == before) continue;
+            rows.push_back(r);
+            off.push_back(q.size());
+        }
+        if (rows.empty()) {                                       // (a single genome: no pairs at all)
+            lock_guard<mutex> lk(mtx); ready.emplace_back(a0, a1); cv.notify_one();
+            continue;
+        }
+        out.resize(q.size());
+        rc = E.group_run_rows(grp, (uint32_t)rows.size(), rows.data(), off.data(), q.data(), out.data());
+        if (rc != LZANI_OK) { cerr << "LZ matching failed: " << E.group_last_error(grp) << endl; ok = false; break; }
+        for (size_t k = 0; k < rows.size(); ++k) {                // into the dense table: row r, query x at x - (x > r)
+            const uint32_t r = rows[k];
+            lzani_result* dst = T.res.data() + T.row_off[r];
+            for (uint64_t e = off[k]; e < off[k + 1]; ++e) { const uint32_t x = q[e]; dst[x < r ? x : x - 1] = out[e]; }
+        }
+        for (size_t d = 0; d < devs.size(); ++d) {
+            lzani_timing t; double gather = 0;
+            if (E.group_get_timing(grp, (uint32_t)d, &t, &gather) == LZANI_OK) {
+                t_index[d] += t.index_ms; t_pairs[d] += t.pairs_ms; t_cand[d] += t.cand_ms + t.kmers_ms; n_pairs[d] += t.pairs;
+                if (d == 0) t_gather += gather;
+            }
+        }
+        { lock_guard<mutex> lk(mtx); ready.emplace_back(a0, a1); }
+        cv.notify_one();
+    }
+    { lock_guard<mutex> lk(mtx); done = true; }
+    cv.notify_one();
+    if (P.verbosity >= 2 && ok) {
+        cerr << "LZ matching done (" << (n + tile - 1) / tile << " blocks of " << tile << " rows); the last rows are being written" << endl;
+        for (size_t d = 0; d < devs.size(); ++d)
+            cerr << "GPU " << devs[d] << ": " << n_pairs[d] << " pairs, index " << t_index[d] << " ms, k-mer words + candidate stage " << t_cand[d]
+                 << " ms, pair kernel " << t_pairs[d] << " ms" << (d == 0 && devs.size() > 1 ? ", gather " + to_string(t_gather) + " ms" : string()) << "\n";
+    }
+    emitter.join();
+    E.group_destroy(grp);
+    return W.close() && ok;
+}
+
 // test seams: the matching stage's integers as text, "ref query mat lit comp" per directed pair
 static bool write_raw(const string& fn, const PairTable& T)
 {
@@ -471,26 +575,41 @@ static bool run_all2all(const char* argv0)
     if (!flt.empty()) { if (P.verbosity >= 1) cerr << "Reordering filter" << endl; reorder_filter(flt, map); }
     stamp("Reordering sequences");
 
-    PairTable results;
-    if (!P.results_in.empty()) { if (!read_raw(P.results_in, g.size(), results)) return false; }
-    else {
-        Engine E;
-        if (!E.load(argv0)) return false;
-        vector<AlnRegion> aln;
-        if (!do_matching(E, g, flt, results, P.out_aln.empty() ? nullptr : &aln)) return false;
-        if (!P.out_aln.empty() && !store_alignment(g, aln)) return false;
-    }
-    stamp("LZ matching");
-    if (!P.results_out.empty() && !write_raw(P.results_out, results)) return false;
-
-    if (P.verbosity >= 1) cerr << "Storing results" << endl;
     EmitParams ep;
     ep.out_name = P.out; ep.ids_name = P.out_ids; ep.single_txt = P.single_txt; ep.in_percent = P.in_percent;
     ep.comps = P.comps; ep.filter_mask = P.flt_mask; memcpy(ep.filter_vals, P.flt_vals, sizeof ep.filter_vals);
     ep.threads = P.threads; ep.mrd = P.lz.max_dist_in_ref;
     if (P.single_txt) ep.params_dump = params_dump();
-    if (!store_results(g, results, ep)) return false;
-    stamp("Storing results");
+
+    // A large dense all2all runs tiled, the result rows of a block written while the next block is matched
+    // (LZANI_TILE_ROWS: rows per block, 0 = never; LZANI_TILE_MIN: genomes from which on)
+    uint32_t tile = 1024, tile_min = 4096;
+    if (const char* e = getenv("LZANI_TILE_ROWS")) tile = (uint32_t)max(0, atoi(e));
+    if (const char* e = getenv("LZANI_TILE_MIN")) tile_min = (uint32_t)max(0, atoi(e));
+    const bool tiled = tile > 0 && P.results_in.empty() && P.out_aln.empty() && flt.empty() && g.size() >= tile_min && g.size() > tile;
+
+    PairTable results;
+    if (!P.results_in.empty()) { if (!read_raw(P.results_in, g.size(), results)) return false; }
+    else {
+        Engine E;
+        if (!E.load(argv0)) return false;
+        if (tiled) {
+            if (P.verbosity >= 1) cerr << "Storing results (row blocks, while the matching goes on)" << endl;
+            if (!do_matching_tiled(E, g, results, ep, tile)) return false;
+        } else {
+            vector<AlnRegion> aln;
+            if (!do_matching(E, g, flt, results, P.out_aln.empty() ? nullptr : &aln)) return false;
+            if (!P.out_aln.empty() && !store_alignment(g, aln)) return false;
+        }
+    }
+    stamp(tiled ? "LZ matching + storing results" : "LZ matching");
+    if (!P.results_out.empty() && !write_raw(P.results_out, results)) return false;
+
+    if (!tiled) {
+        if (P.verbosity >= 1) cerr << "Storing results" << endl;
+        if (!store_results(g, results, ep)) return false;
+        stamp("Storing results");
+    }
 
     if (P.verbosity > 1) {
         ifstream st("/proc/self/status");

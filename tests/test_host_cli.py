@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+import synth_genomes as SG
 import util as U
 
 EXE = os.path.join(U.ROOT, "lz-ani_amd", "host", "lz-ani")
@@ -256,6 +257,37 @@ def test_end_to_end_on_gpu(tmp_path):
     gold = open(os.path.join(U.GOLD, "example", "ani.aln.tsv")).read().split("\n")
     assert got[0] == gold[0] and sorted(got[1:]) == sorted(gold[1:])
     assert open(out).read() == open(os.path.join(U.GOLD, "example", "ani.tsv")).read()
+
+
+@pytest.mark.gpu
+def test_tiled_matching_with_overlapped_emit(tmp_path):
+    """A large dense all2all goes to the engine in row x column blocks and the rows of a finished block are written
+    while the next block is matched (do_matching_tiled): forced here at vir61's size with blocks of 16 rows -- the same
+    bytes as the golden file (= the untiled run), for the standard TSV, the complete format with an --out-filter, and
+    single-txt; one more set (150 genomes, blocks of 40) against the untiled run of the same binary."""
+    env = dict(os.environ, LZANI_TILE_MIN="1", LZANI_TILE_ROWS="16")
+    out = str(tmp_path / "ani.tsv")
+    p = run(["all2all", "--in-dir", os.path.join(U.GOLD, "vir61"), "--out", out, "-V", "2"], env=env)
+    assert p.returncode == 0, p.stderr
+    assert "blocks of 16 rows" in p.stderr
+    assert open(out).read() == open(os.path.join(U.GOLD, "vir61.ani.tsv")).read()
+    assert open(str(tmp_path / "ani.ids.tsv")).read() == open(os.path.join(U.GOLD, "vir61.ani.ids.tsv")).read()
+    names, seqs = SG.make_set(150, 31, lmin=17000, lmax=20000, fam=10)
+    fa = str(tmp_path / "set.fna")
+    with open(fa, "w") as f:
+        for nm, sq in zip(names, seqs):
+            f.write(">" + nm + "\n" + "".join("ACGT"[c] for c in sq) + "\n")
+    for extra in ([], ["--out-format", "complete", "--out-filter", "ani", "0.2"], ["--out-type", "single-txt"]):
+        os.makedirs(str(tmp_path / "a"), exist_ok=True)
+        os.makedirs(str(tmp_path / "b"), exist_ok=True)
+        p = run(["all2all", "--in-fasta", fa, "-o", "out.txt"] + extra, env=dict(os.environ, LZANI_TILE_ROWS="0"), cwd=str(tmp_path / "a"))
+        assert p.returncode == 0, p.stderr
+        p = run(["all2all", "--in-fasta", fa, "-o", "out.txt", "-V", "2"] + extra, env=dict(os.environ, LZANI_TILE_MIN="1", LZANI_TILE_ROWS="40"),
+                cwd=str(tmp_path / "b"))                  # (single-txt echoes the file name among the parameters: the same one in both runs)
+        assert p.returncode == 0 and "blocks of 40 rows" in p.stderr, p.stderr
+        a, b = str(tmp_path / "a" / "out.txt"), str(tmp_path / "b" / "out.txt")
+        assert open(a).read() == open(b).read(), extra
+        assert len(open(a).read()) > 1000
 
 
 def _synth5(tmp_path, n, seed, lmin, lmax, maxfam):

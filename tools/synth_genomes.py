@@ -137,3 +137,20 @@ def make_set_cached(n, seed, cache_dir=None, **kw):
     except OSError:
         pass                                   # (a read-only or full cache directory only costs the next run its minute)
     return names, seqs
+
+
+def write_fasta(path, names, seqs, width=70):
+    lut = np.frombuffer(b"ACGTNN", dtype=np.uint8)
+    with open(path, "wb") as f:
+        for nm, s in zip(names, seqs):
+            f.write(b">" + nm.encode() + b"\n")
+            txt = lut[np.minimum(s, 5)].tobytes()
+            for k in range(0, len(txt), width):
+                f.write(txt[k:k + width] + b"\n")
+
+
+if __name__ == "__main__":
+    import sys
+    n, seed, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    names, seqs = make_set(n, seed)
+    write_fasta(out, names, seqs)
