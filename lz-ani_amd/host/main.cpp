@@ -14,6 +14,7 @@
 #include <deque>
 #include <cstdlib>
 #include <fstream>
+#include <future>
 #include <iterator>
 #include <sstream>
 #include <thread>
@@ -458,43 +459,57 @@ static bool do_matching_tiled(const Engine& E, const vector<Genome>& g, PairTabl
     vector<double> t_index(devs.size(), 0), t_pairs(devs.size(), 0), t_cand(devs.size(), 0);
     vector<uint64_t> n_pairs(devs.size(), 0);
     double t_gather = 0;
-    vector<uint32_t> rows, q;
-    vector<uint64_t> off;
-    vector<lzani_result> out;
-    bool ok = true;
-    for (uint32_t a0 = 0; a0 < n && ok; a0 += tile) {
-        const uint32_t a1 = min(n, a0 + tile);
-        rows.clear(); q.clear(); off.assign(1, 0);
-        for (uint32_t r = a0; r < n; ++r) {
-            const size_t before = q.size();
-            if (r < a1) { for (uint32_t x = a0; x < n; ++x) if (x != r) q.push_back(x); }
-            else for (uint32_t x = a0; x < a1; ++x) q.push_back(x);
-            if (q.size() == before) continue;
-            rows.push_back(r);
-            off.push_back(q.size());
+    // Three sets of buffers: while the GPUs run block k, one host thread lays out the row lists of block k + 1 and another
+    // moves the results of block k - 1 into the table and hands its rows to the emitter.
+    struct Block { uint32_t a0 = 0, a1 = 0; vector<uint32_t> rows, q; vector<uint64_t> off; vector<lzani_result> out; };
+    Block blk[3];
+    const uint32_t n_blocks = (n + tile - 1) / tile;
+    auto build = [&](uint32_t k) {
+        Block& B = blk[k % 3];
+        B.a0 = k * tile; B.a1 = min(n, B.a0 + tile);
+        B.rows.clear(); B.q.clear(); B.off.assign(1, 0);
+        for (uint32_t r = B.a0; r < n; ++r) {
+            const size_t before = B.q.size();
+            if (r < B.a1) { for (uint32_t x = B.a0; x < n; ++x) if (x != r) B.q.push_back(x); }
+            else for (uint32_t x = B.a0; x < B.a1; ++x) B.q.push_back(x);
+            if (B.q.size() == before) continue;
+            B.rows.push_back(r);
+            B.off.push_back(B.q.size());
         }
-        if (rows.empty()) {                                       // (a single genome: no pairs at all)
-            lock_guard<mutex> lk(mtx); ready.emplace_back(a0, a1); cv.notify_one();
-            continue;
-        }
-        out.resize(q.size());
-        rc = E.group_run_rows(grp, (uint32_t)rows.size(), rows.data(), off.data(), q.data(), out.data());
-        if (rc != LZANI_OK) { cerr << "LZ matching failed: " << E.group_last_error(grp) << endl; ok = false; break; }
-        for (size_t k = 0; k < rows.size(); ++k) {                // into the dense table: row r, query x at x - (x > r)
-            const uint32_t r = rows[k];
+        B.out.resize(B.q.size());
+    };
+    auto post = [&](uint32_t k) {
+        Block& B = blk[k % 3];
+        for (size_t i = 0; i < B.rows.size(); ++i) {              // into the dense table: row r, query x at x - (x > r)
+            const uint32_t r = B.rows[i];
             lzani_result* dst = T.res.data() + T.row_off[r];
-            for (uint64_t e = off[k]; e < off[k + 1]; ++e) { const uint32_t x = q[e]; dst[x < r ? x : x - 1] = out[e]; }
+            for (uint64_t e = B.off[i]; e < B.off[i + 1]; ++e) { const uint32_t x = B.q[e]; dst[x < r ? x : x - 1] = B.out[e]; }
         }
-        for (size_t d = 0; d < devs.size(); ++d) {
-            lzani_timing t; double gather = 0;
-            if (E.group_get_timing(grp, (uint32_t)d, &t, &gather) == LZANI_OK) {
-                t_index[d] += t.index_ms; t_pairs[d] += t.pairs_ms; t_cand[d] += t.cand_ms + t.kmers_ms; n_pairs[d] += t.pairs;
-                if (d == 0) t_gather += gather;
+        { lock_guard<mutex> lk(mtx); ready.emplace_back(B.a0, B.a1); }
+        cv.notify_one();
+    };
+    bool ok = true;
+    future<void> f_build, f_post;
+    build(0);
+    for (uint32_t k = 0; k < n_blocks && ok; ++k) {
+        Block& B = blk[k % 3];
+        if (k + 1 < n_blocks) f_build = async(launch::async, build, k + 1);
+        if (!B.rows.empty()) {
+            rc = E.group_run_rows(grp, (uint32_t)B.rows.size(), B.rows.data(), B.off.data(), B.q.data(), B.out.data());
+            if (rc != LZANI_OK) { cerr << "LZ matching failed: " << E.group_last_error(grp) << endl; ok = false; }
+            for (size_t d = 0; d < devs.size() && ok; ++d) {
+                lzani_timing t; double gather = 0;
+                if (E.group_get_timing(grp, (uint32_t)d, &t, &gather) == LZANI_OK) {
+                    t_index[d] += t.index_ms; t_pairs[d] += t.pairs_ms; t_cand[d] += t.cand_ms + t.kmers_ms; n_pairs[d] += t.pairs;
+                    if (d == 0) t_gather += gather;
+                }
             }
         }
-        { lock_guard<mutex> lk(mtx); ready.emplace_back(a0, a1); }
-        cv.notify_one();
+        if (f_build.valid()) f_build.get();
+        if (f_post.valid()) f_post.get();                         // (block k - 1 is out of its buffers before block k + 2 is laid out in them)
+        if (ok) f_post = async(launch::async, post, k);
     }
+    if (f_post.valid()) f_post.get();
     { lock_guard<mutex> lk(mtx); done = true; }
     cv.notify_one();
     if (P.verbosity >= 2 && ok) {
