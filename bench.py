@@ -6,15 +6,16 @@ prints ONE JSON line on rank 0.
 
 Workload = the configuration BASELINE.json's metric is quoted on (configs[2]):
 10,000 synthetic viral genomes of ~40 kbp (tools/synth_genomes.py, seed 2: families of 10, 1-15 %
-divergence), default LZ parameters, dense all2all = 99,990,000 directed pairs -- at EVERY N ("strong"
-scaling: the total work is fixed, the rows are shared out).
+divergence), default LZ parameters, dense all2all = 99,990,000 directed pairs -- at EVERY N; a step holds
+500 rows per rank ("weak" scaling per step: a GPU's batch is what it is in the product whatever N; the job is
+covered in 20 / N steps).
 
-A step = one SLAB of the all2all: 500 consecutive reference rows (in the reference's length-descending
-order) against all other genomes = 4,999,500 directed pairs, i.e. one pass of the hot path over one batch:
-per-reference index build + pair kernel on every rank's share of the slab (rows dealt cyclically over the
+A step = one SLAB of the all2all: 500 consecutive reference rows PER RANK (in the reference's length-descending
+order) against all other genomes = 4,999,500 directed pairs per rank, i.e. one pass of the hot path over one batch:
+per-reference index build + candidate stage + pair kernel on every rank's share of the slab (rows dealt cyclically over the
 ranks by the C-ABI's lzani_partition_rows) + one RCCL all-gather of the per-pair int32[3] records (N > 1:
 torch.distributed's nccl backend by default, `--collective lzani` = lzani_comm_allgather inside the engine
-library, which no pool has yet let run on more than one GPU).  `--steps 20` is exactly one pass over the 10k x 10k matrix; the slabs wrap
+library, which no pool has yet let run on more than one GPU).  `--steps 20` at N = 1 is exactly one pass over the 10k x 10k matrix; the slabs wrap
 around.  Genomes are resident in HBM before the timed region; results stay in HBM.
 
 `roofline` is for the pair kernel (k_pairs): algorithmic bytes B_pair summed over the pairs
@@ -118,7 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--genomes", type=int, default=10000, help="genomes of the set (BASELINE configs[2]: 10,000)")
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--slab", type=int, default=500, help="reference rows per step")
+    ap.add_argument("--slab", type=int, default=500, help="reference rows per step AND RANK (a step = a slab of this many rows times the number of ranks)")
     ap.add_argument("--cpu-sample", type=int, default=192, help="genomes in the CPU baseline sample (0 = skip)")
     ap.add_argument("--lmin", type=int, default=36000, help="ancestor length range of the synthetic set")
     ap.add_argument("--lmax", type=int, default=44000)
@@ -151,7 +152,13 @@ def main():
         else:
             dist.init_process_group(backend="gloo")          # rendezvous, unique id, barriers; the data path is RCCL in the library
 
-    n, slab = args.genomes, max(1, min(args.slab, args.genomes))
+    # rows of a step: `--slab` per rank, so that a rank's share of a step -- one index build, one candidate stage (whose cost
+    # does not shrink with the rows), one pair-kernel launch -- is the same at every N, as in the product, where a GPU works
+    # through its share of the matrix in batches of hundreds of rows whatever the number of GPUs ("weak" per step; the job
+    # stays the 10,000 x 10,000 all2all, covered in 20 / N steps)
+    n = args.genomes
+    slab_rank = max(1, min(args.slab, args.genomes))
+    slab = max(1, min(slab_rank * world, args.genomes))
     over = {k: int(v) for k, v in (kv.split("=") for kv in args.params.split(",") if kv)}
     names, seqs = SG.make_set_cached(n, args.seed, lmin=args.lmin, lmax=args.lmax)
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
@@ -250,14 +257,15 @@ def main():
         out = {
             "metric": "genome-pairs/sec + achieved HBM GB/s, 10k×40kbp all2all at 1/2/4/8 GPUs",
             "value": value, "unit": "genome-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (2-bit packed symbols, 64-bit lane masks; f64 only in the anchor/seed arbitration)",
             "data": "synthetic",
             "config": {"workload": f"{n} synthetic genomes of {args.lmin}-{args.lmax} bp (families of 10, 1-15% divergence, seed {args.seed}), "
                                    f"dense all2all ({n * (n - 1)} directed pairs per pass), "
-                                   f"{'default LZ params' if not over else 'LZ params ' + args.params}; one step = a slab of {slab} reference rows "
-                                   f"x all other genomes = {slab * (n - 1)} directed pairs, {(n + slab - 1) // slab} steps per pass",
-                       "genomes": n, "seed": args.seed, "pairs_per_pass": n * (n - 1), "slab_rows": slab, "pairs_per_step": slab * (n - 1),
+                                   f"{'default LZ params' if not over else 'LZ params ' + args.params}; one step = a slab of {slab_rank} reference rows "
+                                   f"per rank ({slab} rows in all) x all other genomes = {slab * (n - 1)} directed pairs, {(n + slab - 1) // slab} steps per pass",
+                       "genomes": n, "seed": args.seed, "pairs_per_pass": n * (n - 1), "slab_rows": slab, "slab_rows_per_rank": slab_rank,
+                       "pairs_per_step": slab * (n - 1),
                        "pairs_timed": total_pairs, "pairs_timed_rank0": my_pairs,
                        "sharding": (f"rows of a slab dealt cyclically over {world} ranks (lzani_partition_rows), genomes replicated, one RCCL "
                                     f"all-gather of int32[3] per pair per step ({coll_name})")
@@ -268,7 +276,7 @@ def main():
                                       "block_kernel_with_lds_filter": int(lay["block_launches"] > 0),
                                       "candidate_bitmaps_from_presence_matrix": int(lay["bitmap_launches"] > 0)}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.seed, slab, world),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.seed, slab_rank, world),
                          "kernel": kernel_name, "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": abytes / launches,
                          "index_build_ms_per_step": index_ms / args.steps, "candidate_stage_ms_per_step": cand_ms / args.steps},
