@@ -23,7 +23,7 @@ __device__ int g_guard_trip = 0;   // see LZ_GUARD_TRIP in lzani_core.h
 __device__ unsigned long long g_stamp_acc[8];
 #endif
 #ifdef LZANI_CHAIN_STATS
-__device__ unsigned long long g_chain_stats[12];
+__device__ unsigned long long g_chain_stats[16];
 #endif
 
 int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_t n, int begin_bit, int end_bit,
@@ -849,13 +849,15 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 #endif
 #ifdef LZANI_CHAIN_STATS
     {
-        unsigned long long acc[12], z[12] = {0};
+        unsigned long long acc[16], z[16] = {0};
         HIPCHK(c, hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_chain_stats), sizeof acc));
         const char* nm[8] = {"chain_calls", "commits", "exit_nothing", "exit_seed", "exit_not_plain", "exit_event", "events_general", "refills"};
         fprintf(stderr, "[lzani chain] pairs=%llu per pair:", (unsigned long long)n_pairs);
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.1f", nm[k], (double)acc[k] / (double)n_pairs);
         fprintf(stderr, "\n[lzani chain] wave cycles per pair: after exit_nothing=%.0f after round_done=%.0f after exit_event=%.0f inside the chain=%.0f\n",
                 (double)acc[8] / (double)n_pairs, (double)acc[9] / (double)n_pairs, (double)acc[10] / (double)n_pairs, (double)acc[11] / (double)n_pairs);
+        fprintf(stderr, "[lzani chain] events found but not null, per pair: close=%.1f region kept or none open=%.1f no forward record=%.1f backward side=%.1f\n",
+                (double)acc[12] / (double)n_pairs, (double)acc[13] / (double)n_pairs, (double)acc[14] / (double)n_pairs, (double)acc[15] / (double)n_pairs);
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stats), z, sizeof z));
     }
 #endif

@@ -59,6 +59,7 @@ struct DevWave {
     unsigned st[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // diagnostic build: chain calls, commits, exits by kind, events by the general path, refills
     // wave cycles between two null_chain calls by what the first one handed back (0 nothing, 1 round done, 2 event found),
     // slot 3 = inside null_chain itself; stc_open = the slot the running interval belongs to
+    unsigned sr[4] = {0, 0, 0, 0};                  // events found but not null, by reason: close, region kept (or none open), no forward record, backward
     unsigned long long stc[4] = {0, 0, 0, 0}, stc_t0 = 0;
     int stc_open = -2;
     __device__ __forceinline__ void cycles_mark(int code)
@@ -990,6 +991,13 @@ struct DevWave {
         if (code == 2) { adv = ap - i; last_src = q_head++; }
 #ifdef LZANI_CHAIN_STATS
         st[0] += 1; st[1] += ncnt; st[2] += code == 0; st[3] += code == 1 && seed != 0; st[4] += code == 1 && seed == 0; st[5] += code == 2;
+        if (code == 2) {                      // why the event found is not a null event (first reason that applies)
+            const int g2 = ap - i;
+            const bool close = g2 <= MQD && iabs(bpos - (r_end + g2)) <= MRD;
+            const bool kept = prev_rs < 0 || prev_re - prev_rs >= REG;
+            const bool nofwd = !((u32)rec & EXT_REC_FWDK);
+            sr[0] += close; sr[1] += !close && kept; sr[2] += !close && !kept && nofwd; sr[3] += !close && !kept && !nofwd;
+        }
 #endif
         return code;
     }
@@ -1314,6 +1322,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
 #ifdef LZANI_CHAIN_STATS
     for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[k], lane == 0 ? (unsigned long long)w.st[k] : 0ULL);
     for (int k = 0; k < 4; ++k) atomicAdd(&g_chain_stats[8 + k], lane == 0 ? w.stc[k] : 0ULL);
+    for (int k = 0; k < 4; ++k) atomicAdd(&g_chain_stats[12 + k], lane == 0 ? (unsigned long long)w.sr[k] : 0ULL);
 #endif
 #ifdef LZANI_STAMPS
     w.stamp(0);
