@@ -188,13 +188,16 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--genomes", "240", "--seed", "9", "--slab", "50", "--lmin", "3000", "--lmax", "5000", "--collective", "gloo", "--device", "0"]
+           "--genomes", "300", "--seed", "9", "--slab", "50", "--lmin", "3000", "--lmax", "5000", "--collective", "gloo", "--device", "0"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.split("\n") if ln.startswith("{")][0]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity_on_last_slab"] == "bit-exact"
-    assert d["config"]["pairs_timed"] == 3 * 50 * 239 and d["config"]["pairs_timed_rank0"] == 3 * 25 * 239
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["parity_on_last_slab"] == "bit-exact"
+    # a step = 50 rows per rank: 100 rows in all, dealt cyclically; the per-rank split of the timed region is there for both ranks
+    assert d["config"]["pairs_timed"] == 3 * 100 * 299 and d["config"]["pairs_timed_rank0"] == 3 * 50 * 299
+    assert d["config"]["slab_rows"] == 100 and d["config"]["slab_rows_per_rank"] == 50
+    assert all(len(d["per_rank_ms_per_step"][k]["by_rank"]) == 2 for k in ("compute_ms", "kernel_ms", "fixed_ms", "gather_ms"))
 
 
 def test_group_gather_plan_against_python_statement():
