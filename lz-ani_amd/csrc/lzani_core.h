@@ -746,14 +746,15 @@ struct PairMachine {
                 // short region" for as many events as it lasts: exactly the updates of the null event below, nothing
                 // else touched; what it leaves unfinished it hands back (the round done, or the event found).
                 if (trk & (lit == 0)) {
-                    int last_cl = 0, last_clit = 0;
+                    int last_cl = 0, last_clit = 0, add_tm = 0, add_tl = 0, add_tc = 0;
 #if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
                     w.cycles_mark(-1);                                 // wave cycles by what the chain handed back: closes the open interval
 #endif
-                    in_hand = w.null_chain(i, r_end, prev_rs, prev_re, pre_lit, last_cl, last_clit, adv, bpos, blen);
+                    in_hand = w.null_chain(i, r_end, prev_rs, prev_re, pre_lit, last_cl, last_clit, adv, bpos, blen, g.cl, g.clit, add_tm, add_tl, add_tc);
 #if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
                     w.cycles_mark(in_hand);
 #endif
+                    g.tm += add_tm; g.tl += add_tl; g.tc += add_tc;             // regions the chain closed (kept ones it passed)
                     if (last_cl) { g.cl = last_cl; g.clit = last_clit; g.nl = 0; }  // discard + the match (+ forward extension) of the last event
                 }
             }

@@ -733,10 +733,15 @@ struct DevWave {
     //   returns 1   the tracking round of step i is done: pre_seed / pre_rk0 / pre_rk1 / pre_qk, for find_event
     //   returns 2   the next event is found but is not a null event: adv, bpos, blen (consumed from the queue)
     // i, r_end, prev_rs, prev_re, pre_lit are the machine's; last_cl != 0 = events were committed, the open region is the
-    // last one's match and forward extension (cl = last_cl, clit = last_clit, nl = 0).  Wait states of gfx950 are placed by hand
+    // last one's match and forward extension (cl = last_cl, clit = last_clit, nl = 0).  A null event over a region that is
+    // KEPT (its query span reached reg: seed events grew it) or over none is committed as well: the kept region --
+    // (open_cl, open_clit) at the call, the last committed event's afterwards -- is closed the way calc_stats closes it
+    // at a match_distant factor, into add_tm / add_tl / add_tc (the machine adds them to its totals), and the candidate
+    // looks back over the literals since the last match only.  Wait states of gfx950 are placed by hand
     // (VALU-written mask -> VALU use: 2; lane select / VMEM base written by a VALU: the prologue is long enough).
     __device__ __forceinline__ int null_chain(int& i, int& r_end, int& prev_rs, int& prev_re, int& pre_lit, int& last_cl,
-                                              int& last_clit, int& adv, int& bpos, int& blen)
+                                              int& last_clit, int& adv, int& bpos, int& blen, int open_cl, int open_clit,
+                                              int& add_tm, int& add_tl, int& add_tc)
     {
         static_assert(!CHAIN || (FAST && BK), "the null chain reads the anchor queue");
         enum { MQD = 40, MRD = 40, MSL = 7, REG = 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };    // params.h:34-48
@@ -839,10 +844,15 @@ struct DevWave {
             "s_add_i32 %[qh], %[qh], 1\n\t" \
             LZ_NC_COUNT
         int gap, cls, fok;
+        // (the machine's accumulators may live in vector registers -- they come out of popcounts: as scalars for the loop)
+        const int ocl_u = __builtin_amdgcn_readfirstlane(open_cl), oclit_u = __builtin_amdgcn_readfirstlane(open_clit);
         asm volatile(
             "s_mov_b32 %[code], 0\n\t"
             "s_mov_b32 %[lastb], 0\n\t"
             "s_mov_b32 %[lastlit], 0\n\t"
+            "s_mov_b32 %[atm], 0\n\t"
+            "s_mov_b32 %[atl], 0\n\t"
+            "s_mov_b32 %[atc], 0\n\t"
             "s_nop 3\n"
             "Lnc_top_%=:\n\t"
             // the queue head: candidates the last match has passed go
@@ -878,15 +888,17 @@ struct DevWave {
             "s_cmp_le_i32 %[gap], %[MQD]\n\t"
             "s_cbranch_scc1 Lnc_close_%=\n"
             "Lnc_distant_%=:\n\t"
+            "s_mov_b32 %[cls], 0\n\t"                        // (1 = the open region is kept, or there is none)
             "s_cmp_lt_i32 %[prs], 0\n\t"
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_cbranch_scc1 Lnc_kept_%=\n\t"
             "s_sub_i32 %[t1], %[pre], %[prs]\n\t"
             "s_cmp_ge_i32 %[t1], %[REG]\n\t"
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_cbranch_scc1 Lnc_kept_%=\n\t"
             "s_bitcmp0_b32 %[rec], 29\n\t"                  // the forward extension must be in the record (empty or not)
             "s_cbranch_scc1 Lnc_chk_%=\n\t"
             "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
-            "s_add_i32 %[t1], %[t1], %[plit]\n\t"           // avail
+            "s_add_i32 %[t1], %[t1], %[plit]\n"             // avail: the dropped region and the literals before it
+            "Lnc_avail_%=:\n\t"
             "s_min_i32 %[t0], %[t1], %[ap]\n\t"
             "s_min_i32 %[t0], %[t0], %[bpos]\n\t"           // reach
             "s_mov_b32 %[kb], 0\n\t"                          // the backward extension: empty, unless the record holds it
@@ -921,6 +933,24 @@ struct DevWave {
             "s_mov_b32 %[code], 2\n\t"
             "s_cmp_eq_u32 %[t2], 0\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the event is found but is not a null event
+            "s_cmp_eq_u32 %[cls], 0\n\t"
+            "s_cbranch_scc1 Lnc_commit_%=\n\t"
+            // the open region is kept (not dropped): calc_stats' step at the match_distant factor that follows -- it counts
+            // if its matches and literals reach reg (parser.cpp:743-751, 775).  The open region is the last committed
+            // event's if this call has committed any, else the machine's
+            "s_cmp_lg_u32 %[lastb], 0\n\t"
+            "s_cselect_b32 %[t0], %[lastb], %[ocl]\n\t"
+            "s_cselect_b32 %[t2], %[lastlit], %[oclit]\n\t"
+            "s_cmp_eq_u32 %[t0], 0\n\t"
+            "s_cbranch_scc1 Lnc_commit_%=\n\t"
+            "s_add_i32 %[t2], %[t2], %[t0]\n\t"
+            "s_cmp_lt_i32 %[t2], %[REG]\n\t"
+            "s_cbranch_scc1 Lnc_commit_%=\n\t"
+            "s_sub_i32 %[t2], %[t2], %[t0]\n\t"
+            "s_add_i32 %[atm], %[atm], %[t0]\n\t"
+            "s_add_i32 %[atl], %[atl], %[t2]\n\t"
+            "s_add_i32 %[atc], %[atc], 1\n"
+            "Lnc_commit_%=:\n\t"
             LZ_NC_COMMIT
             "s_mov_b32 %[code], 0\n\t"
             "s_cmp_eq_u32 %[fok], 0\n\t"
@@ -954,6 +984,12 @@ struct DevWave {
             "Lnc_fseed_%=:\n\t"                             // a seed candidate: as above (the queue head is the successor)
             "s_mov_b32 %[code], 1\n\t"
             "s_branch Lnc_end_%=\n"
+            "Lnc_kept_%=:\n\t"                              // no region to drop: the candidate may look back over the literals since
+            "s_mov_b32 %[cls], 1\n\t"                        // the last match only (avail = lit), the rest is the same
+            "s_bitcmp0_b32 %[rec], 29\n\t"
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+            "s_mov_b32 %[t1], %[gap]\n\t"
+            "s_branch Lnc_avail_%=\n"
             "Lnc_close_%=:\n\t"                             // a tracking step: close to the predicted position = not ours
             "s_add_i32 %[t1], %[rend], %[gap]\n\t"
             "s_sub_i32 %[t1], %[bpos], %[t1]\n\t"
@@ -967,9 +1003,9 @@ struct DevWave {
             : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit),
               [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec),
               [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [m] "=&s"(m), [seed] "=&s"(seed),
-              [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok),
+              [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc),
               [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq)
-            : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks),
+            : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [ocl] "s"(ocl_u), [oclit] "s"(oclit_u),
               [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), [scrw] "v"(scrw),
               [ldsb] "v"(ldsb), [zero] "v"(zero),
               [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [W1] "n"(WIN - 1), [NR1] "n"(WIN - 64)
