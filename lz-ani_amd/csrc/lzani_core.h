@@ -594,6 +594,11 @@ LZ_HD bool ext_rec_bwd_known(u32 rec, int reach, int aw, int& b, int& c)
 template <class W, class = void> struct wave_has_null_chain : std::false_type {};
 template <class W> struct wave_has_null_chain<W, std::void_t<decltype(W::NULL_CHAIN)>> : std::bool_constant<W::NULL_CHAIN> {};
 
+// a policy may fetch three forward mismatch masks in one go (DevWave::mism3: the two diagonals of a gap fill and the first
+// chunk of the forward extension behind the close match -- one memory wait instead of two)
+template <class W, class = void> struct wave_has_mism3 : std::false_type {};
+template <class W> struct wave_has_mism3<W, std::void_t<decltype(W::HAS_MISM3)>> : std::bool_constant<W::HAS_MISM3> {};
+
 template <class W, bool ALN = false>
 struct PairMachine {
     W& w;
@@ -695,7 +700,9 @@ struct PairMachine {
     }
 
     // compare_ranges_both_ways folded (parser.cpp:251-374); len = literal run <= 64
-    LZ_HD void gap_fill(int ds, int r_left, int r_right_end, int len)
+    // fq / fr / nf / Bf: the first chunk of the forward extension behind the close match, fetched with the gap's two
+    // diagonals where the policy can (haveF says whether it was)
+    LZ_HD void gap_fill(int ds, int r_left, int r_right_end, int len, int fq = 0, int fr = 0, int nf = 0, u64* Bf = nullptr, bool* haveF = nullptr)
     {
         if (len <= 0) return;
         int to_scan = (r_right_end < r_left) ? len : imin(r_right_end - r_left, len);
@@ -703,6 +710,10 @@ struct PairMachine {
         u64 F = 0;
         if (to_scan > 0) {
             u64 Lm, Rm;
+            if constexpr (wave_has_mism3<W>::value && !ALN) {
+                if (Bf) { w.mism3(ds, r_left, to_scan, ds + shift, r_right_end - to_scan, to_scan, fq, fr, nf, Lm, Rm, *Bf); *haveF = true; }
+                else w.mism2(ds, r_left, 1, to_scan, ds + shift, r_right_end - to_scan, 1, to_scan, Lm, Rm);
+            } else
             w.mism2(ds, r_left, 1, to_scan, ds + shift, r_right_end - to_scan, 1, to_scan, Lm, Rm);
             Lm = ~Lm & lowmask(to_scan);
             Rm = ~Rm & lowmask(to_scan);
@@ -780,7 +791,10 @@ struct PairMachine {
             bool haveF = false;
             if (strk && iabs(bpos - ref_pred) <= P.mrd) {
                 // close match: fill the gap, then the match itself (parser.cpp:630-635; quirk Q2)
-                gap_fill(i - lit, r_end, bpos + blen, lit);
+                if constexpr (wave_has_mism3<W>::value && !ALN) {
+                    fq = i + blen; fr = bpos + blen;
+                    gap_fill(i - lit, r_end, bpos + blen, lit, fq, fr, imax(0, imin(64, imin(D - fq, T - fr))), &Bf, &haveF);
+                } else gap_fill(i - lit, r_end, bpos + blen, lit);
                 match_run(i, bpos, blen);
             } else {
                 // distant match (parser.cpp:636-685)

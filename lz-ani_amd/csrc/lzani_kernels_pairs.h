@@ -172,6 +172,25 @@ struct DevWave {
         A = wballot((lane < na) & ma);
         B = wballot((lane < nb) & mb);
     }
+    // three forward masks, six independent loads in flight, one wait (a close match: the two diagonals of its gap fill and
+    // the first chunk of the forward extension behind it)
+    static constexpr bool HAS_MISM3 = true;
+    __device__ __forceinline__ void mism3(int qa, int ra, int na, int qb, int rb, int nb, int qc, int rc, int nc, u64& A, u64& B, u64& C) const
+    {
+        bool ma, mb, mc;
+        if (R.nfree && Q.nfree) {
+            SymReq x = sym_request(ra + lane, qa + lane), y = sym_request(rb + lane, qb + lane), z = sym_request(rc + lane, qc + lane);
+            asm volatile("" : "+v"(x.wr), "+v"(x.wq), "+v"(y.wr), "+v"(y.wq), "+v"(z.wr), "+v"(z.wq));
+            ma = sym_differs(x); mb = sym_differs(y); mc = sym_differs(z);
+        } else {
+            ma = !sym_match(R, ra + lane, Q, qa + lane);
+            mb = !sym_match(R, rb + lane, Q, qb + lane);
+            mc = !sym_match(R, rc + lane, Q, qc + lane);
+        }
+        A = wballot((lane < na) & ma);
+        B = wballot((lane < nb) & mb);
+        C = wballot((lane < nc) & mc);
+    }
     // Close-seed search of the tracking steps of a round (replaces the ht_short bucket walk, parser.cpp:548-580).
     // rk0/rk1 = msl-mers of the window positions r_end+lane / r_end+64+lane, qk = msl-mer of this lane's step
     // (KM_INVALID where there is none).
@@ -1209,8 +1228,15 @@ struct DevWave {
         int key = -1;
         if (lane <= to_scan) key = (popc64(Lm & lowmask(lane)) + popc64(Rm >> lane)) * 128 + lane;
         if (to_scan == 64) key = imax(key, popc64(Lm) * 128 + 64);
-        for (int d = 32; d >= 1; d >>= 1) key = imax(key, __shfl_xor(key, d));
-        return key & 127;
+        // the wave's maximum by DPP (prefix maxima inside the rows of 16, then the row broadcasts: lane 63 holds it) -- six
+        // vector instructions instead of six round trips through the LDS crossbar (ds_bpermute)
+        key = imax(key, __builtin_amdgcn_update_dpp(-1, key, 0x111, 0xF, 0xF, false));
+        key = imax(key, __builtin_amdgcn_update_dpp(-1, key, 0x112, 0xF, 0xF, false));
+        key = imax(key, __builtin_amdgcn_update_dpp(-1, key, 0x114, 0xF, 0xF, false));
+        key = imax(key, __builtin_amdgcn_update_dpp(-1, key, 0x118, 0xF, 0xF, false));
+        key = imax(key, __builtin_amdgcn_update_dpp(-1, key, 0x142, 0xA, 0xF, false));
+        key = imax(key, __builtin_amdgcn_update_dpp(-1, key, 0x143, 0xC, 0xF, false));
+        return __builtin_amdgcn_readlane(key, 63) & 127;
     }
 };
 
