@@ -1074,7 +1074,25 @@ struct DevWave {
         u64 seedmask = 0;
         const bool pre = CHAIN && pre_round;                         // null_chain has done this call's tracking round (and found
         pre_round = false;                                           // a seed candidate or a candidate that is not plain)
-        if (pre) { seedmask = pre_seed; rk0 = pre_rk0; rk1 = pre_rk1; qk = pre_qk; round_done = true; }
+        if (pre) {
+            seedmask = pre_seed; rk0 = pre_rk0; rk1 = pre_rk1; qk = pre_qk; round_done = true;
+            // The chain's usual reason to hand a round back: a seed candidate at a step before the next queued anchor, one
+            // window position carrying the step's k-mer -- that step is the event (no anchor there to arbitrate with, and
+            // a seed is at least msl long): straight down, without the loop below.
+            if (seedmask) {
+                const int ls = ctz64(seedmask);
+                const int la = q_head < q_cnt ? __builtin_amdgcn_readlane(a_pos, q_head) - i : 64;
+                if (ls < la) {
+                    u64 d0, d1;
+                    seed_candidates((u32)__builtin_amdgcn_readlane((int)qk, ls), lit + ls + P.mrd, rk0, rk1, d0, d1);
+                    if (popc64(d0) + popc64(d1) == 1) {
+                        const int idx = d0 ? ctz64(d0) : 64 + ctz64(d1);
+                        adv = ls; bpos = r_end + idx; blen = wave_equal_len(bpos, i + ls, P.msl);
+                        return true;
+                    }
+                }
+            }
+        }
         else if (__builtin_expect(!refill_now, 1)) {
             // The common call, straight down, no loop: one round over the tracking steps (close seeds as in
             // find_event_round) and, when none of them has a seed candidate (four rounds out of five of an unrelated
