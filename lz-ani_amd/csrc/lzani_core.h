@@ -320,6 +320,9 @@ LZ_HD void arbitrate(const Params& P, int T, int lit, int ap, int al, int& sp, i
 {
     if (!ap) return;
     if (!sp) { sp = ap; sl = al; return; }
+    // the anchor IS the close seed (the window holds the anchor's position: the continuation of a related stretch): the
+    // comparison of the two probabilities cannot change anything -- and it is ~18 rounds of f64 multiplies per power
+    if (sp == ap && sl == al) return;
     u32 ea = (u32)(int)(2 * ((u64)T + 1 - (u64)(int64_t)al));     // (int) cast, then uint32_t parameter (Q4)
     u32 ec = (u32)(lit + P.mrd + 1 - sl);
     double anchor_prob = pow_not_chance(al, ea);

@@ -694,16 +694,17 @@ struct DevWave {
     // which of the steps [i, i + nt), nt <= 64, are candidates (have an anchor): the detect of refill for one chunk, nothing
     // resolved.  For tracking rounds the queue does not cover -- the scan has jumped over it, i.e. an extension moved: a
     // related stretch, where every position is a candidate and resolving 64 of them per event would be wasted.
-    __device__ __forceinline__ u64 detect_steps(int i, int nt) const
+    // (probe form: the steps [from, nt) only -- a lane outside makes no request, and every probe is a 128-byte line)
+    __device__ __forceinline__ u64 detect_steps(int i, int nt, int from = 0) const
     {
         if (JOIN) {
             const int sh = i & 63;
             const unsigned long long wd = cand_bits[((u32)i >> 6) + (u32)imin(lane, 1)];
-            return ((bcast64(wd, 0) >> sh) | ((bcast64(wd, 1) << 1) << (63 - sh))) & lowmask(nt);
+            return ((bcast64(wd, 0) >> sh) | ((bcast64(wd, 1) << 1) << (63 - sh))) & lowmask(nt) & ~lowmask(from);
         }
         const int tb = I.kb - I.dirbits;
         const u32 hq = qkL[(u32)(i + lane)];
-        const bool valid = (lane < nt) & (hq != KM_INVALID);
+        const bool valid = (lane >= from) & (lane < nt) & (hq != KM_INVALID);
         const u32 w = I.tw[valid ? hq >> tb : 0u];
         const u32 x = w ^ rep4(0x80u | (hq & I.tagmask));
         const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
@@ -1119,11 +1120,17 @@ struct DevWave {
             // candidates per event where every position is one would be wasted.  Kept apart from the loop below so that
             // neither shapes the other's registers.
             seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk);
-            u64 lightmask = detect_steps(i, nt);
+            // The anchors of the steps are probed only as far as they can matter: up to the first step with a seed
+            // candidate (a seed is an event: nothing behind it is reached), else the first eight steps, the rest only if
+            // none of those hits.  In a related stretch the event is at the first steps, and each probe spared is a
+            // 128-byte line of a table that 20 references per XCD share an L2 with (this kernel waits for memory).
+            int known = JOIN ? nt : imin(nt, seedmask ? ctz64(seedmask) + 1 : 8);
+            u64 lightmask = detect_steps(i, known);
             for (int it = 0; it < 130; ++it) {
                 const int ls = seedmask ? ctz64(seedmask) : 64;
                 const int la = lightmask ? ctz64(lightmask) : 64;
                 const int l = imin(ls, la);
+                if (l >= known && known < nt) { lightmask |= detect_steps(i, nt, known); known = nt; continue; }
                 if (l >= 64) break;
                 const int qp = i + l;
                 int ap = 0, al = 0;
