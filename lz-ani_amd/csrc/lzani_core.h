@@ -773,7 +773,7 @@ struct PairMachine {
                 }
             }
             w.stamp(4);
-            const bool hit = in_hand == 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);
+            const bool hit = in_hand >= 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);   // (2, 4: the chain found the event)
 #if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
             w.st[6] += hit && in_hand != 2;
 #endif

@@ -752,6 +752,8 @@ struct DevWave {
     //   returns 0   nothing in hand (queue empty or not covering the tracking steps, query or reference end near)
     //   returns 1   the tracking round of step i is done: pre_seed / pre_rk0 / pre_rk1 / pre_qk, for find_event
     //   returns 2   the next event is found but is not a null event: adv, bpos, blen (consumed from the queue)
+    //   returns 4   the tracking round of step i found a seed candidate and the event is simple (see Lnc_seedev): adv,
+    //               bpos, blen are the close match's, nothing consumed from the queue
     // i, r_end, prev_rs, prev_re, pre_lit are the machine's; last_cl != 0 = events were committed, the open region is the
     // last one's match and forward extension (cl = last_cl, clit = last_clit, nl = 0).  A null event over a region that is
     // KEPT (its query span reached reg: seed events grew it) or over none is committed as well: the kept region --
@@ -864,6 +866,12 @@ struct DevWave {
             "s_add_i32 %[qh], %[qh], 1\n\t" \
             LZ_NC_COUNT
         int gap, cls, fok;
+        u64 m2;
+        // the packed texts as 32-bit words (16 symbols each) and the end of the scan -- far below zero for a pair with an N in
+        // it, which the loop's own seed event does not take (its lanes carry no bounds)
+        const u32* const rt2 = uniform_ptr(reinterpret_cast<const u32*>(R.t2));
+        const u32* const qt2 = uniform_ptr(reinterpret_cast<const u32*>(Q.t2));
+        const int qend = __builtin_amdgcn_readfirstlane((R.nfree && Q.nfree) ? iend : -(1 << 30));
         // (the machine's accumulators may live in vector registers -- they come out of popcounts: as scalars for the loop)
         const int ocl_u = __builtin_amdgcn_readfirstlane(open_cl), oclit_u = __builtin_amdgcn_readfirstlane(open_clit);
         asm volatile(
@@ -947,7 +955,7 @@ struct DevWave {
             LZ_NC_ROUND
             "s_mov_b32 %[code], 1\n\t"
             LZ_NC_SEEDS
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // a seed candidate: the round is done, the rest is find_event's
+            "s_cbranch_scc1 Lnc_seedev_%=\n\t"              // a seed candidate: the round is done; the event itself, if it is simple
             "s_cmp_lt_i32 %[blen], 1\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the candidate is not plain: likewise
             "s_mov_b32 %[code], 2\n\t"
@@ -1002,7 +1010,89 @@ struct DevWave {
             LZ_NC_COMMIT
             "s_branch Lnc_fast_%=\n"
             "Lnc_fseed_%=:\n\t"                             // a seed candidate: as above (the queue head is the successor)
-            "s_mov_b32 %[code], 1\n\t"
+            "s_mov_b32 %[code], 1\n"
+            // The seed event (code = 1 here; every way out before the last line leaves it so, and seed / rk0 / rk1 / qk
+            // untouched: find_event then does the same from the round).  The simple case is found here: the first step with
+            // a seed candidate lies before the queued candidate's, ONE window position carries its msl-mer, the 64 symbols
+            // behind the msl-mer are real symbols of one strand on both sides (no lane needs a bound) and hold a mismatch:
+            // that is the event -- a seed is at least msl long and no anchor stands at its step to arbitrate with
+            // (parser.cpp:548-580, 604-606) -- adv = the step, bpos, blen = msl + the matching symbols behind.
+            "Lnc_seedev_%=:\n\t"
+            "s_ff1_i32_b64 %[t0], %[m]\n\t"                 // l
+            "s_cmp_eq_u32 %[t0], %[gap]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the queued candidate's own step: arbitration
+            "v_readlane_b32 %[t1], %[qk], %[t0]\n\t"        // the step's msl-mer
+            "s_add_i32 %[t2], %[t0], %[MRD]\n\t"            // its window: the positions idx < l + mrd
+            "s_sub_i32 %[kc], %[t2], 64\n\t"
+            "s_max_i32 %[kc], %[kc], 0\n\t"
+            "s_min_u32 %[kb], %[t2], 64\n\t"
+            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk0]\n\t"
+            "v_cmp_eq_u32_e64 %[m], %[t1], %[rk1]\n\t"
+            "s_bfm_b64 %[m2], %[kc], 0\n\t"
+            "s_and_b64 %[m], %[m], %[m2]\n\t"
+            "s_cmp_eq_u32 %[kb], 64\n\t"
+            "s_cbranch_scc1 Lnc_sd1_%=\n\t"
+            "s_bfm_b64 %[m2], %[kb], 0\n\t"
+            "s_and_b64 vcc, vcc, %[m2]\n"
+            "Lnc_sd1_%=:\n\t"
+            "s_bcnt1_i32_b64 %[kb], vcc\n\t"
+            "s_bcnt1_i32_b64 %[kc], %[m]\n\t"
+            "s_add_i32 %[t2], %[kb], %[kc]\n\t"
+            "s_cmp_lg_u32 %[t2], 1\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // several window positions: the longest, then the nearest (find_event)
+            "s_ff1_i32_b64 %[t2], vcc\n\t"
+            "s_ff1_i32_b64 %[t1], %[m]\n\t"
+            "s_add_i32 %[t1], %[t1], 64\n\t"
+            "s_cmp_lg_u32 %[kb], 0\n\t"
+            "s_cselect_b32 %[t2], %[t2], %[t1]\n\t"         // idx
+            "s_add_i32 %[rec], %[rend], %[t2]\n\t"          // the seed in the reference ...
+            "s_add_i32 %[cls], %[i], %[t0]\n\t"             // ... and in the query
+            // bounds: query [cls + 7, cls + 71) inside [0, Lq), Lq = qend - 33 (qend = the scan's end D - msl = Lq + mrd - msl; a pair
+            // with an N in it has qend far below zero); reference the same inside [0, L) or [rc0, rc0 + L), L = (rlim - 34) / 2
+            // (rlim = 2 L + 3 mrd - msl + 1 - 80), rc0 = L + 2 mrd
+            "s_sub_i32 %[t1], %[qend], 104\n\t"
+            "s_cmp_gt_i32 %[cls], %[t1]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_sub_i32 %[t1], %[rlim], 34\n\t"
+            "s_lshr_b32 %[t1], %[t1], 1\n\t"
+            "s_add_i32 %[t2], %[rec], 71\n\t"
+            "s_cmp_le_i32 %[t2], %[t1]\n\t"
+            "s_cbranch_scc1 Lnc_sok_%=\n\t"
+            "s_add_i32 %[kb], %[t1], 80\n\t"                // rc0
+            "s_cmp_lt_i32 %[rec], %[kb]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // runs from the forward strand into the pad
+            "s_add_i32 %[kb], %[kb], %[t1]\n\t"
+            "s_cmp_gt_i32 %[t2], %[kb]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n"
+            "Lnc_sok_%=:\n\t"
+            "s_add_i32 %[t1], %[rec], 7\n\t"
+            "s_add_i32 %[t2], %[cls], 7\n\t"
+            "v_add_u32_e32 %[a0], %[t1], %[lane]\n\t"
+            "v_add_u32_e32 %[a1], %[t2], %[lane]\n\t"
+            "v_lshrrev_b32_e32 %[aq], 4, %[a0]\n\t"
+            "v_lshrrev_b32_e32 %[t], 4, %[a1]\n\t"
+            "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t"
+            "v_lshlrev_b32_e32 %[t], 2, %[t]\n\t"
+            "global_load_dword %[aq], %[aq], %[rt2]\n\t"
+            "global_load_dword %[t], %[t], %[qt2]\n\t"
+            "v_and_b32_e32 %[a0], 15, %[a0]\n\t"
+            "v_and_b32_e32 %[a1], 15, %[a1]\n\t"
+            "v_lshlrev_b32_e32 %[a0], 1, %[a0]\n\t"
+            "v_lshlrev_b32_e32 %[a1], 1, %[a1]\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            "v_lshrrev_b32_e32 %[aq], %[a0], %[aq]\n\t"
+            "v_lshrrev_b32_e32 %[t], %[a1], %[t]\n\t"
+            "v_xor_b32_e32 %[aq], %[aq], %[t]\n\t"
+            "v_and_b32_e32 %[aq], 3, %[aq]\n\t"
+            "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t"
+            "s_nop 0\n\t"
+            "s_cmp_eq_u64 %[m], 0\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // 64 more symbols match: the general path measures on
+            "s_ff1_i32_b64 %[blen], %[m]\n\t"
+            "s_add_i32 %[blen], %[blen], 7\n\t"
+            "s_mov_b32 %[ap], %[t0]\n\t"
+            "s_mov_b32 %[bpos], %[rec]\n\t"
+            "s_mov_b32 %[code], 4\n\t"
             "s_branch Lnc_end_%=\n"
             "Lnc_kept_%=:\n\t"                              // no region to drop: the candidate may look back over the literals since
             "s_mov_b32 %[cls], 1\n\t"                        // the last match only (avail = lit), the rest is the same
@@ -1023,9 +1113,10 @@ struct DevWave {
             : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit),
               [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec),
               [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [m] "=&s"(m), [seed] "=&s"(seed),
-              [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc),
+              [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc), [m2] "=&s"(m2),
               [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq)
             : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [ocl] "s"(ocl_u), [oclit] "s"(oclit_u),
+              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend),
               [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), [scrw] "v"(scrw),
               [ldsb] "v"(ldsb), [zero] "v"(zero),
               [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [W1] "n"(WIN - 1), [NR1] "n"(WIN - 64)
@@ -1045,6 +1136,7 @@ struct DevWave {
         pre_round = code == 1;
         pre_seed = seed; pre_rk0 = rk0; pre_rk1 = rk1; pre_qk = qk;
         if (code == 2) { adv = ap - i; last_src = q_head++; }
+        if (code == 4) { adv = ap; last_src = -1; }          // the seed event: bpos, blen are the loop's
 #ifdef LZANI_CHAIN_STATS
         st[0] += 1; st[1] += ncnt; st[2] += code == 0; st[3] += code == 1 && seed != 0; st[4] += code == 1 && seed == 0; st[5] += code == 2;
         if (code == 2) {                      // why the event found is not a null event (first reason that applies)
