@@ -1092,8 +1092,189 @@ struct DevWave {
             "s_add_i32 %[blen], %[blen], 7\n\t"
             "s_mov_b32 %[ap], %[t0]\n\t"
             "s_mov_b32 %[bpos], %[rec]\n\t"
-            "s_mov_b32 %[code], 4\n\t"
-            "s_branch Lnc_end_%=\n"
+            "s_mov_b32 %[code], 4\n\t"                      // from here on the event is known: any way out hands it to the machine
+            // The close match itself (PairMachine::run: gap_fill, match_run, the first chunk of extend_forward), when every
+            // symbol it looks at is a real symbol of one strand and the forward extension breaks inside its first chunk.
+            // What it does to the open region (cl, clit; nl = 0 before and after): the gap's l symbols give `score` matches
+            // -- the best split's count, compare_ranges_both_ways (parser.cpp:251-374); which split wins a tie only matters to
+            // the alignment output -- and l - score literals, the match blen matches, the extension e - mm and mm.
+            //   t0 = l, rec = the seed in the reference, cls = in the query;  t1 = fq, fok = fr (behind the match)
+            "s_add_i32 %[t1], %[cls], %[blen]\n\t"
+            "s_add_i32 %[t2], %[t1], 64\n\t"
+            "s_sub_i32 %[kb], %[qend], 33\n\t"              // Lq
+            "s_cmp_gt_i32 %[t2], %[kb]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_add_i32 %[fok], %[rec], %[blen]\n\t"
+            "s_add_i32 %[t2], %[fok], 64\n\t"               // the reference side: [rend, fr + 64) on one strand
+            "s_sub_i32 %[kb], %[rlim], 34\n\t"
+            "s_lshr_b32 %[kb], %[kb], 1\n\t"                // L
+            "s_cmp_le_i32 %[t2], %[kb]\n\t"
+            "s_cbranch_scc1 Lnc_hull_%=\n\t"
+            "s_add_i32 %[kc], %[kb], 80\n\t"                // rc0
+            "s_cmp_lt_i32 %[rend], %[kc]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_add_i32 %[kc], %[kc], %[kb]\n\t"
+            "s_cmp_gt_i32 %[t2], %[kc]\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n"
+            "Lnc_hull_%=:\n\t"
+            // to_scan = min(fr - rend, l), shift = l - to_scan; left diagonal (rend, i), right (fr - to_scan, i + shift)
+            "s_sub_i32 %[kb], %[fok], %[rend]\n\t"
+            "s_min_i32 %[kb], %[kb], %[t0]\n\t"             // to_scan (0 when the seed sits at the first step)
+            "s_sub_i32 %[kc], %[t0], %[kb]\n\t"
+            "s_sub_i32 %[gap], %[fok], %[kb]\n\t"           // right diagonal: reference start
+            "s_add_i32 %[kc], %[kc], %[i]\n\t"              //                 query start
+            // six words in flight: the word's byte address ((pos >> 4) << 2) worked out in the register the word lands in
+            "v_add_u32_e32 %[rk0], %[rend], %[lane]\n\t"
+            "v_add_u32_e32 %[rk1], %[i], %[lane]\n\t"
+            "v_add_u32_e32 %[qk], %[gap], %[lane]\n\t"
+            "v_add_u32_e32 %[a0], %[kc], %[lane]\n\t"
+            "v_add_u32_e32 %[a1], %[fok], %[lane]\n\t"
+            "v_add_u32_e32 %[aq], %[t1], %[lane]\n\t"
+            "v_lshrrev_b32_e32 %[rk0], 4, %[rk0]\n\t"
+            "v_lshrrev_b32_e32 %[rk1], 4, %[rk1]\n\t"
+            "v_lshrrev_b32_e32 %[qk], 4, %[qk]\n\t"
+            "v_lshrrev_b32_e32 %[a0], 4, %[a0]\n\t"
+            "v_lshrrev_b32_e32 %[a1], 4, %[a1]\n\t"
+            "v_lshrrev_b32_e32 %[aq], 4, %[aq]\n\t"
+            "v_lshlrev_b32_e32 %[rk0], 2, %[rk0]\n\t"
+            "v_lshlrev_b32_e32 %[rk1], 2, %[rk1]\n\t"
+            "v_lshlrev_b32_e32 %[qk], 2, %[qk]\n\t"
+            "v_lshlrev_b32_e32 %[a0], 2, %[a0]\n\t"
+            "v_lshlrev_b32_e32 %[a1], 2, %[a1]\n\t"
+            "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t"
+            "s_nop 0\n\t"
+            "global_load_dword %[rk0], %[rk0], %[rt2]\n\t"
+            "global_load_dword %[rk1], %[rk1], %[qt2]\n\t"
+            "global_load_dword %[qk], %[qk], %[rt2]\n\t"
+            "global_load_dword %[a0], %[a0], %[qt2]\n\t"
+            "global_load_dword %[a1], %[a1], %[rt2]\n\t"
+            "global_load_dword %[aq], %[aq], %[qt2]\n\t"
+            "s_bfm_b64 %[seed], %[kb], 0\n\t"               // the to_scan lanes of the gap's diagonals (to_scan <= 40)
+            "s_waitcnt vmcnt(0)\n\t"
+            // left diagonal -> m = its matches
+            "v_add_u32_e32 %[t], %[rend], %[lane]\n\t"
+            "v_add_u32_e32 %[bq], %[i], %[lane]\n\t"
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t"
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t"
+            "v_and_b32_e32 %[t], 30, %[t]\n\t"
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t"
+            "v_lshrrev_b32_e32 %[rk0], %[t], %[rk0]\n\t"
+            "v_lshrrev_b32_e32 %[rk1], %[bq], %[rk1]\n\t"
+            "v_xor_b32_e32 %[rk0], %[rk0], %[rk1]\n\t"
+            "v_and_b32_e32 %[rk0], 3, %[rk0]\n\t"
+            "v_cmp_eq_u32_e64 %[m], 0, %[rk0]\n\t"
+            // right diagonal -> m2
+            "v_add_u32_e32 %[t], %[gap], %[lane]\n\t"
+            "v_add_u32_e32 %[bq], %[kc], %[lane]\n\t"
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t"
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t"
+            "v_and_b32_e32 %[t], 30, %[t]\n\t"
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t"
+            "v_lshrrev_b32_e32 %[qk], %[t], %[qk]\n\t"
+            "v_lshrrev_b32_e32 %[a0], %[bq], %[a0]\n\t"
+            "v_xor_b32_e32 %[qk], %[qk], %[a0]\n\t"
+            "v_and_b32_e32 %[qk], 3, %[qk]\n\t"
+            "v_cmp_eq_u32_e64 %[m2], 0, %[qk]\n\t"
+            // forward chunk -> vcc = its MISmatches
+            "v_add_u32_e32 %[t], %[fok], %[lane]\n\t"
+            "v_add_u32_e32 %[bq], %[t1], %[lane]\n\t"
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t"
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t"
+            "v_and_b32_e32 %[t], 30, %[t]\n\t"
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t"
+            "v_lshrrev_b32_e32 %[a1], %[t], %[a1]\n\t"
+            "v_lshrrev_b32_e32 %[aq], %[bq], %[aq]\n\t"
+            "v_xor_b32_e32 %[a1], %[a1], %[aq]\n\t"
+            "v_and_b32_e32 %[a1], 3, %[a1]\n\t"
+            "v_cmp_ne_u32_e32 vcc, 0, %[a1]\n\t"
+            "s_and_b64 %[m], %[m], %[seed]\n\t"             // Lm
+            "s_and_b64 %[m2], %[m2], %[seed]\n\t"           // Rm
+            "s_mov_b64 %[seed], vcc\n\t"                    // Bf
+            // best split: lane s scores popc(Lm below s) + popc(Rm from s on) for s <= to_scan; the maximum is what counts
+            "s_bcnt1_i32_b64 %[t2], %[m2]\n\t"
+            "s_mov_b64 vcc, %[m]\n\t"
+            "s_nop 0\n\t"
+            "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
+            "s_mov_b64 vcc, %[m2]\n\t"
+            "s_nop 0\n\t"
+            "v_mbcnt_lo_u32_b32 %[bq], vcc_lo, 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[bq], vcc_hi, %[bq]\n\t"
+            "v_add_u32_e32 %[t], %[t2], %[t]\n\t"
+            "v_sub_u32_e32 %[t], %[t], %[bq]\n\t"
+            "v_cmp_ge_u32_e32 vcc, %[kb], %[lane]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e32 %[t], 0, %[t], vcc\n\t"      // (a split beyond to_scan scores nothing)
+            "s_nop 1\n\t"
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "s_nop 1\n\t"
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "s_nop 1\n\t"
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "s_nop 1\n\t"
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+            "s_nop 1\n\t"
+            "v_max_u32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_u32_dpp %[t], %[t], %[t] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_readlane_b32 %[t2], %[t], 63\n\t"            // score
+            // the forward extension's first chunk (try_extend_forward, parser.cpp:377-409; ext_lane): symbol j breaks the scan
+            // if the 15 symbols ending at it hold more than 7 mismatches, and qualifies if it and the two before it match.
+            // The window of lane j = bits [j, j + 15) of Bf << 14, as three words e0 (gap), e1 (kc), e2 (kb)
+            "s_mov_b64 vcc, %[seed]\n\t"
+            "s_lshl_b32 %[gap], vcc_lo, 14\n\t"
+            "s_lshr_b32 %[kb], vcc_lo, 18\n\t"
+            "s_lshl_b32 %[kc], vcc_hi, 14\n\t"
+            "s_or_b32 %[kc], %[kc], %[kb]\n\t"
+            "s_lshr_b32 %[kb], vcc_hi, 18\n\t"
+            "v_mov_b32_e32 %[rk0], %[gap]\n\t"
+            "v_mov_b32_e32 %[rk1], %[kc]\n\t"
+            "v_mov_b32_e32 %[qk], %[kb]\n\t"
+            "v_cmp_gt_u32_e32 vcc, 32, %[lane]\n\t"
+            "v_alignbit_b32 %[a0], %[rk1], %[rk0], %[lane]\n\t"
+            "v_alignbit_b32 %[a1], %[qk], %[rk1], %[lane]\n\t"
+            "v_cndmask_b32_e32 %[a0], %[a1], %[a0], vcc\n\t"
+            "v_and_b32_e32 %[a0], 0x7fff, %[a0]\n\t"
+            "v_bcnt_u32_b32 %[a1], %[a0], 0\n\t"
+            "v_and_b32_e32 %[a0], 0x7000, %[a0]\n\t"
+            "v_cmp_lt_u32_e32 vcc, 7, %[a1]\n\t"            // brk
+            "v_cmp_eq_u32_e64 %[m], 0, %[a0]\n\t"           // qual
+            "s_nop 0\n\t"
+            "s_cmp_eq_u64 vcc, 0\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // no break inside the chunk: the extension runs on (the general path)
+            "s_ff1_i32_b64 %[kb], vcc\n\t"
+            "s_cmp_ge_u32 %[kb], 63\n\t"
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+            "s_add_i32 %[kb], %[kb], 1\n\t"
+            "s_bfm_b64 %[m2], %[kb], 0\n\t"
+            "s_and_b64 %[m], %[m], %[m2]\n\t"               // qualifying symbols up to the break
+            "s_mov_b32 %[kb], 0\n\t"                         // e
+            "s_mov_b32 %[kc], 0\n\t"                         // mm
+            "s_cbranch_scc0 Lnc_sext_%=\n\t"
+            "s_flbit_i32_b64 %[kb], %[m]\n\t"
+            "s_sub_i32 %[kb], 64, %[kb]\n\t"                // e = the last qualifying symbol + 1
+            "s_bfm_b64 %[m2], %[kb], 0\n\t"
+            "s_and_b64 %[m2], %[m2], %[seed]\n\t"
+            "s_bcnt1_i32_b64 %[kc], %[m2]\n"                 // mm: the mismatches among its e symbols
+            "Lnc_sext_%=:\n\t"
+            // commit: the open region (the last committed event's, else the machine's) grows by the gap, the match, the extension
+            "s_cmp_lg_u32 %[lastb], 0\n\t"
+            "s_cselect_b32 %[gap], %[lastb], %[ocl]\n\t"
+            "s_cselect_b32 %[rec], %[lastlit], %[oclit]\n\t"
+            "s_add_i32 %[gap], %[gap], %[t2]\n\t"           // + score
+            "s_add_i32 %[gap], %[gap], %[blen]\n\t"
+            "s_add_i32 %[gap], %[gap], %[kb]\n\t"
+            "s_sub_i32 %[lastb], %[gap], %[kc]\n\t"         // cl += score + blen + e - mm
+            "s_add_i32 %[rec], %[rec], %[t0]\n\t"
+            "s_sub_i32 %[rec], %[rec], %[t2]\n\t"
+            "s_add_i32 %[lastlit], %[rec], %[kc]\n\t"       // clit += l - score + mm
+            "s_add_i32 %[i], %[t1], %[kb]\n\t"
+            "s_add_i32 %[rend], %[fok], %[kb]\n\t"
+            "s_mov_b32 %[pre], %[i]\n\t"
+            "s_mov_b32 %[code], 0\n\t"
+            LZ_NC_COUNT
+            "s_branch Lnc_top_%=\n"
             "Lnc_kept_%=:\n\t"                              // no region to drop: the candidate may look back over the literals since
             "s_mov_b32 %[cls], 1\n\t"                        // the last match only (avail = lit), the rest is the same
             "s_bitcmp0_b32 %[rec], 29\n\t"
