@@ -625,7 +625,7 @@ struct DevWave {
     // j's match and forward extension) and bit 15 (GO) = that candidate is the next null event, for certain: j's
     // tracking round is complete (query and reference ends far enough), the region j opened is short (dropped), the
     // successor is plain, distant from j, its record holds both extensions and it sits at least aw symbols into both
-    // texts.  (Then its reach is >= aw as well: what it may look back at grows from event to event while regions are
+    // texts (that last property of a candidate alone is bit 16: the general turn's short cut).  (Then its reach is >= aw as well: what it may look back at grows from event to event while regions are
     // dropped.)  Only "no seed candidate in j's tracking round" is left to the loop.  The parameters are the defaults.
     __device__ __forceinline__ void chain_classes()
     {
@@ -652,7 +652,7 @@ struct DevWave {
         const int gap = s_pos - end;
         const bool distant = (gap > MQD) | (iabs((s_u & 0x7FFFFFFF) - (rend + gap)) > MRD);
         const bool go = pred & (succ < q_cnt) & (s_u < 0) & distant;
-        a_len = (len & 0xFF) | (succ << 8) | (go ? 0x8000 : 0);
+        a_len = (len & 0xFF) | (succ << 8) | (go ? 0x8000 : 0) | (cap ? 0x10000 : 0);
     }
     __device__ __forceinline__ bool ext_record(u32& x) const
     {
@@ -909,6 +909,7 @@ struct DevWave {
             "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
             "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
             "s_mov_b32 %[t2], 0\n\t"
+            "s_bfe_u32 %[code], %[blen], 0x10010\n\t"       // chain_classes' bit 16: plain, both extensions in the record, aw symbols into both texts
             "s_sext_i32_i8 %[blen], %[blen]\n\t"            // (the rest of the word is chain_classes')
             "s_sub_i32 %[gap], %[ap], %[i]\n\t"
             "s_cmp_lt_i32 %[blen], 1\n\t"
@@ -922,11 +923,22 @@ struct DevWave {
             "s_sub_i32 %[t1], %[pre], %[prs]\n\t"
             "s_cmp_ge_i32 %[t1], %[REG]\n\t"
             "s_cbranch_scc1 Lnc_kept_%=\n\t"
-            "s_bitcmp0_b32 %[rec], 29\n\t"                  // the forward extension must be in the record (empty or not)
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
             "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
             "s_add_i32 %[t1], %[t1], %[plit]\n"             // avail: the dropped region and the literals before it
             "Lnc_avail_%=:\n\t"
+            // the short cut: the candidate's own properties are in bit 16; with at least aw symbols to look back at, its
+            // reach is >= aw and the backward extension is the record's
+            "s_cmp_eq_u32 %[code], 0\n\t"
+            "s_cbranch_scc1 Lnc_gen_%=\n\t"
+            "s_cmp_lt_i32 %[t1], %[AW]\n\t"
+            "s_cbranch_scc1 Lnc_gen_%=\n\t"
+            "s_and_b32 %[kb], %[rec], 15\n\t"
+            "s_bfe_u32 %[kc], %[rec], 0x40004\n\t"
+            "s_mov_b32 %[fok], 1\n\t"
+            "s_branch Lnc_ok_%=\n"
+            "Lnc_gen_%=:\n\t"
+            "s_bitcmp0_b32 %[rec], 29\n\t"                  // the forward extension must be in the record (empty or not)
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
             "s_min_i32 %[t0], %[t1], %[ap]\n\t"
             "s_min_i32 %[t0], %[t0], %[bpos]\n\t"           // reach
             "s_mov_b32 %[kb], 0\n\t"                          // the backward extension: empty, unless the record holds it
@@ -1277,8 +1289,6 @@ struct DevWave {
             "s_branch Lnc_top_%=\n"
             "Lnc_kept_%=:\n\t"                              // no region to drop: the candidate may look back over the literals since
             "s_mov_b32 %[cls], 1\n\t"                        // the last match only (avail = lit), the rest is the same
-            "s_bitcmp0_b32 %[rec], 29\n\t"
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
             "s_mov_b32 %[t1], %[gap]\n\t"
             "s_branch Lnc_avail_%=\n"
             "Lnc_close_%=:\n\t"                             // a tracking step: close to the predicted position = not ours
