@@ -999,10 +999,16 @@ struct DevWave {
             // chain_classes' word says which entry the scan meets next and whether that is the next null event for
             // certain (GO) -- then only this entry's tracking round is left to do
             "Lnc_fast_%=:\n\t"
-            "s_sub_i32 %[t2], %[qh], 1\n\t"
+            // (inside a run of fast turns the machine's state is kept as far as the turns need it: i, rend, the queue head;
+            // what the general turn and the seed event need besides -- prs, plit, pre, the open region -- is a function of
+            // the last committed entry and of fok = prs - plit, the same for every null event over a dropped region, and is
+            // rebuilt when the run ends, Lnc_frec)
+            "s_sub_i32 %[fok], %[prs], %[plit]\n"
+            "Lnc_fturn_%=:\n\t"
+            "s_sub_i32 %[t2], %[qh], 1\n\t"                // the last committed entry (t2 stays untouched to the end of the turn)
             "v_readlane_b32 %[cls], %[alen], %[t2]\n\t"
             "s_bitcmp0_b32 %[cls], 15\n\t"
-            "s_cbranch_scc1 Lnc_top_%=\n\t"
+            "s_cbranch_scc1 Lnc_frec_%=\n\t"
             "s_bfe_u32 %[qh], %[cls], 0x70008\n\t"          // the successor (the entries between are passed)
             LZ_NC_LOADS
             "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
@@ -1011,16 +1017,38 @@ struct DevWave {
             "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
             "s_sext_i32_i8 %[blen], %[blen]\n\t"
             "s_sub_i32 %[gap], %[ap], %[i]\n\t"
-            "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
-            "s_add_i32 %[t1], %[t1], %[plit]\n\t"           // avail
-            "s_and_b32 %[kb], %[rec], 15\n\t"
-            "s_bfe_u32 %[kc], %[rec], 0x40004\n\t"
             LZ_NC_ROUND
             "s_nop 0\n\t"
             LZ_NC_SEEDS
-            "s_cbranch_scc1 Lnc_fseed_%=\n\t"
-            LZ_NC_COMMIT
-            "s_branch Lnc_fast_%=\n"
+            "s_cbranch_scc1 Lnc_frec_%=\n\t"               // a seed candidate: the state first, then the seed event
+            "s_bfe_u32 %[t0], %[rec], 0x50018\n\t"          // e
+            "s_add_i32 %[t0], %[t0], %[blen]\n\t"
+            "s_add_i32 %[i], %[ap], %[t0]\n\t"
+            "s_add_i32 %[rend], %[bpos], %[t0]\n\t"
+            "s_add_i32 %[qh], %[qh], 1\n\t"
+            LZ_NC_COUNT
+            "s_branch Lnc_fturn_%=\n"
+            // the machine's state after the null event of entry t2 (see LZ_NC_COMMIT): avail = apos - fok
+            "Lnc_frec_%=:\n\t"
+            "v_readlane_b32 %[t0], %[apos], %[t2]\n\t"
+            "v_readlane_b32 %[t1], %[alen], %[t2]\n\t"
+            "v_readlane_b32 %[kc], %[aext], %[t2]\n\t"
+            "s_sext_i32_i8 %[t1], %[t1]\n\t"
+            "s_and_b32 %[kb], %[kc], 15\n\t"
+            "s_sub_i32 %[prs], %[t0], %[kb]\n\t"
+            "s_sub_i32 %[plit], %[t0], %[fok]\n\t"
+            "s_sub_i32 %[plit], %[plit], %[kb]\n\t"
+            "s_bfe_u32 %[lastlit], %[kc], 0x40014\n\t"
+            "s_bfe_u32 %[t0], %[kc], 0x50018\n\t"
+            "s_add_i32 %[t1], %[t1], %[t0]\n\t"
+            "s_sub_i32 %[lastb], %[t1], %[lastlit]\n\t"
+            "s_bfe_u32 %[t0], %[kc], 0x40004\n\t"
+            "s_add_i32 %[lastb], %[lastb], %[t0]\n\t"
+            "s_add_i32 %[lastlit], %[lastlit], %[kb]\n\t"
+            "s_sub_i32 %[lastlit], %[lastlit], %[t0]\n\t"
+            "s_mov_b32 %[pre], %[i]\n\t"
+            "s_bitcmp0_b32 %[cls], 15\n\t"
+            "s_cbranch_scc1 Lnc_top_%=\n"                   // the run ended at an entry that is not GO: the general turn
             "Lnc_fseed_%=:\n\t"                             // a seed candidate: as above (the queue head is the successor)
             "s_mov_b32 %[code], 1\n"
             // The seed event (code = 1 here; every way out before the last line leaves it so, and seed / rk0 / rk1 / qk
