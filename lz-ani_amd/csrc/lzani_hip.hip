@@ -23,7 +23,7 @@ __device__ int g_guard_trip = 0;   // see LZ_GUARD_TRIP in lzani_core.h
 __device__ unsigned long long g_stamp_acc[8];
 #endif
 #ifdef LZANI_CHAIN_STATS
-__device__ unsigned long long g_chain_stats[16];
+__device__ unsigned long long g_chain_stats[24];
 #endif
 
 int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_t n, int begin_bit, int end_bit,
@@ -849,7 +849,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 #endif
 #ifdef LZANI_CHAIN_STATS
     {
-        unsigned long long acc[16], z[16] = {0};
+        unsigned long long acc[24], z[24] = {0};
         HIPCHK(c, hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_chain_stats), sizeof acc));
         const char* nm[8] = {"chain_calls", "commits", "exit_nothing", "exit_seed", "exit_not_plain", "exit_event", "events_general", "refills"};
         fprintf(stderr, "[lzani chain] pairs=%llu per pair:", (unsigned long long)n_pairs);
@@ -858,6 +858,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 (double)acc[8] / (double)n_pairs, (double)acc[9] / (double)n_pairs, (double)acc[10] / (double)n_pairs, (double)acc[11] / (double)n_pairs);
         fprintf(stderr, "[lzani chain] events found but not null, per pair: close=%.1f region kept or none open=%.1f no forward record=%.1f backward side=%.1f\n",
                 (double)acc[12] / (double)n_pairs, (double)acc[13] / (double)n_pairs, (double)acc[14] / (double)n_pairs, (double)acc[15] / (double)n_pairs);
+        fprintf(stderr, "[lzani chain] exit_seed by the test that handed the round back, per pair: anchor's own step=%.1f no window position=%.1f several=%.1f text end=%.1f long seed=%.1f other=%.1f; event known, commit left=%.1f\n",
+                (double)acc[16] / (double)n_pairs, (double)acc[17] / (double)n_pairs, (double)acc[18] / (double)n_pairs, (double)acc[19] / (double)n_pairs,
+                (double)acc[20] / (double)n_pairs, (double)acc[21] / (double)n_pairs, (double)acc[22] / (double)n_pairs);
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stats), z, sizeof z));
     }
 #endif

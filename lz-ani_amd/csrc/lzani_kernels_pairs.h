@@ -16,7 +16,10 @@ enum { SEED_BM_BITS = 14, SEED_BM_WORDS = 1 << (SEED_BM_BITS - 5), NQUEUES = 8 }
 // detected ahead of the scan in chunks of 64 query positions, at most AQ_MAXCHUNKS per refill, and compacted
 // through 2 x AQ_LDS_CAND words of LDS (positions, bucket slots) -- the first words of the wave's seed bitmap, which no
 // round is using while a refill runs and which the refill leaves all zero again (2 KB of LDS per wave in all)
-enum { AQ_CAP = 64, AQ_MAXCHUNKS = 32, AQ_LANE_CAP = 32, AQ_LDS_CAND = 128, SEED_LDS_WORDS = SEED_BM_WORDS };
+enum { AQ_CAP = 64, AQ_MAXCHUNKS = 32, AQ_LANE_CAP = 32, AQ_LDS_CAND = 128,
+       SEED_PAD = 96,                 // words behind a wave's bitmap: 64 that take what the null chain's lanes without a k-mer write
+                                      // (one per lane: LDS atomics on one address serialise), then one they read (always zero)
+       SEED_LDS_WORDS = SEED_BM_WORDS + SEED_PAD };
 static_assert(2 * AQ_LDS_CAND <= SEED_BM_WORDS, "the candidate buffers of refill live in the seed bitmap");
 enum : u32 { AQ_COMPLEX = 0x80000000u, AQ_LONG = 0x40000000u, AQ_POS = 0x3FFFFFFFu };
 enum { AQ_NONE = 0x7FFFFFFF };
@@ -59,6 +62,7 @@ struct DevWave {
     unsigned st[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // diagnostic build: chain calls, commits, exits by kind, events by the general path, refills
     // wave cycles between two null_chain calls by what the first one handed back (0 nothing, 1 round done, 2 event found),
     // slot 3 = inside null_chain itself; stc_open = the slot the running interval belongs to
+    unsigned sw[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // exit_seed by reason (see null_chain)
     unsigned sr[4] = {0, 0, 0, 0};                  // events found but not null, by reason: close, region kept (or none open), no forward record, backward
     unsigned long long stc[4] = {0, 0, 0, 0}, stc_t0 = 0;
     int stc_open = -2;
@@ -652,7 +656,7 @@ struct DevWave {
         const int gap = s_pos - end;
         const bool distant = (gap > MQD) | (iabs((s_u & 0x7FFFFFFF) - (rend + gap)) > MRD);
         const bool go = pred & (succ < q_cnt) & (s_u < 0) & distant;
-        a_len = (len & 0xFF) | (succ << 8) | (go ? 0x8000 : 0) | (cap ? 0x10000 : 0);
+        a_len = (len & 0xFF) | (succ << 8) | (go ? 0x8000 : 0) | (cap ? 0x10000 : 0) | ((t2 & 0xFF) << 17);      // (t2 <= 127 + 31)
     }
     __device__ __forceinline__ bool ext_record(u32& x) const
     {
@@ -770,7 +774,6 @@ struct DevWave {
         const int ilim = imin(scan_pos, iend) - NT;             // the queue and the query cover the tracking steps of i <= ilim
         const int rlim = R.len - MSL + 1 - WIN;                 // the seed window of r_end <= rlim is complete
         const u32 ldsb = (u32)(size_t)bitmap;                   // LDS byte offset (low half of the flat address)
-        const u32 scrw = (u32)lane;                             // a lane's own scratch word (see seed_prefilter)
         const u32 zero = 0;
         const u32* const qks = uniform_ptr(qkS);
         const u32* const rks = uniform_ptr(rkS);
@@ -784,69 +787,73 @@ struct DevWave {
 #else
         const int qc_u = q_cnt, ilim_u = ilim, rlim_u = rlim;
 #endif
-        u32 rk0, rk1, qk, a0, a1, aq, t, bq;
+        u32 rk0, rk1, qk, a0, a1, aq, t, bq, w1, dumv;
 #ifdef LZANI_CHAIN_STATS
         int ncnt = 0;
 #define LZ_NC_COUNT "s_add_i32 %[ncnt], %[ncnt], 1\n\t"
-#define LZ_NC_COUNT_OPERAND [ncnt] "+s"(ncnt),
+        int why = 0;                                // which test of the loop's seed event handed the round back (exit_seed)
+#define LZ_NC_COUNT_OPERAND [ncnt] "+s"(ncnt), [why] "+s"(why),
+#define LZ_NC_WHY(n) "s_mov_b32 %[why], " #n "\n\t"
 #else
 #define LZ_NC_COUNT
 #define LZ_NC_COUNT_OPERAND
+#define LZ_NC_WHY(n)
 #endif
 #if defined(LZANI_EXP) && LZANI_EXP == 4           // diagnostic build (wrong results): seed candidates ignored inside the chain
 #define LZ_NC_NOSEED "s_cmp_lg_u32 0, 0\n\t"
 #else
 #define LZ_NC_NOSEED
 #endif
-        // the three loads of a tracking round (msl-mers of the 41 steps and of the 80 window positions) and its lane masks
-#define LZ_NC_LOADS \
+        // the three loads of a tracking round (msl-mers of the 41 steps and of the 80 window positions).  The lanes beyond
+        // (steps >= NT, window positions >= WIN) are not masked: their steps are cut from the result (LZ_NC_SEEDS), their
+        // window positions are positions of the first load again; what leaves the loop with the round in hand is masked then (LZ_NC_FIX)
+#define LZ_NC_LOADS_F \
             "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t" \
             "v_add_lshl_u32 %[a1], %[lane], %[rend], 2\n\t" \
-            "v_or_b32_e32 %[aq], 64, %[lane]\n\t" \
-            "v_min_u32_e32 %[aq], %[W1], %[aq]\n\t" \
-            "v_add_lshl_u32 %[aq], %[aq], %[rend], 2\n\t" \
+            "v_add_lshl_u32 %[aq], %[w1], %[rend], 2\n\t" \
             "global_load_dword %[qk], %[a0], %[qks]\n\t" \
             "global_load_dword %[rk0], %[a1], %[rks]\n\t" \
-            "global_load_dword %[rk1], %[aq], %[rks]\n\t" \
-            "v_cmp_gt_u32_e32 vcc, %[NT], %[lane]\n\t" \
-            "v_cmp_gt_u32_e64 %[m], %[NR1], %[lane]\n\t"
+            "global_load_dword %[rk1], %[aq], %[rks]\n\t"
         // the round itself (track_round + seed_prefilter): window k-mers into the LDS bitmap, every step tests its own, the
-        // bits are cleared again; leaves the steps with a seed candidate in m & vcc
-#define LZ_NC_ROUND \
+        // bits are cleared again; leaves the steps with a seed candidate in seed.  A lane without a k-mer (KM_INVALID >> 5 is
+        // beyond every word of the bitmap) writes to the first word behind the bitmap and reads the second one, which stays
+        // zero (SEED_PAD): no lane select, no mask
+#define LZ_NC_ROUND_F \
             "s_waitcnt vmcnt(0)\n\t" \
-            "v_cndmask_b32_e32 %[qk], -1, %[qk], vcc\n\t" \
-            "v_cndmask_b32_e64 %[rk1], -1, %[rk1], %[m]\n\t" \
-            "v_cmp_eq_u32_e32 vcc, -1, %[rk0]\n\t" \
             "v_lshrrev_b32_e32 %[a0], 5, %[rk0]\n\t" \
             "v_lshlrev_b32_e64 %[t], %[rk0], 1\n\t" \
-            "v_cndmask_b32_e32 %[a0], %[a0], %[scrw], vcc\n\t" \
-            "v_cndmask_b32_e64 %[t], %[t], 0, vcc\n\t" \
-            "v_cmp_eq_u32_e64 %[m], -1, %[rk1]\n\t" \
+            "v_min_u32_e32 %[a0], %[dumv], %[a0]\n\t" \
             "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t" \
             "ds_or_b32 %[a0], %[t]\n\t" \
             "v_lshrrev_b32_e32 %[a1], 5, %[rk1]\n\t" \
             "v_lshlrev_b32_e64 %[bq], %[rk1], 1\n\t" \
-            "v_cndmask_b32_e64 %[a1], %[a1], %[scrw], %[m]\n\t" \
-            "v_cndmask_b32_e64 %[bq], %[bq], 0, %[m]\n\t" \
-            "v_cmp_ne_u32_e32 vcc, -1, %[qk]\n\t" \
+            "v_min_u32_e32 %[a1], %[dumv], %[a1]\n\t" \
             "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t" \
             "ds_or_b32 %[a1], %[bq]\n\t" \
             "v_lshrrev_b32_e32 %[aq], 5, %[qk]\n\t" \
             "v_lshlrev_b32_e64 %[t], %[qk], 1\n\t" \
-            "v_cndmask_b32_e32 %[aq], %[scrw], %[aq], vcc\n\t" \
+            "v_min_u32_e32 %[aq], %[wzero], %[aq]\n\t" \
             "v_lshl_add_u32 %[aq], %[aq], 2, %[ldsb]\n\t" \
             "ds_read_b32 %[aq], %[aq]\n\t" \
             "ds_write_b32 %[a0], %[zero]\n\t" \
             "ds_write_b32 %[a1], %[zero]\n\t" \
             "s_waitcnt lgkmcnt(2)\n\t" \
             "v_and_b32_e32 %[aq], %[aq], %[t]\n\t" \
-            "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t"
+            "v_cmp_ne_u32_e64 %[seed], 0, %[aq]\n\t"
+        // the lane masks a round went without, for what leaves the loop with the round in hand (find_event, the seed event)
+#define LZ_NC_FIX \
+            "s_bfm_b64 %[m2], %[NT], 0\n\t" \
+            "s_and_b64 %[seed], %[seed], %[m2]\n\t" \
+            "v_cmp_gt_u32_e64 %[m2], %[NR1], %[lane]\n\t" \
+            "v_cmp_gt_u32_e32 vcc, %[NT], %[lane]\n\t" \
+            "s_nop 1\n\t" \
+            "v_cndmask_b32_e64 %[rk1], -1, %[rk1], %[m2]\n\t" \
+            "v_cndmask_b32_e32 %[qk], -1, %[qk], vcc\n"
         // a seed candidate matters only up to the step of the queued candidate itself (gap steps ahead): m = the steps
         // with a seed candidate among them (scc = any); seed keeps them all for find_event
 #define LZ_NC_SEEDS \
-            "s_and_b64 %[seed], %[m], vcc\n\t" \
             "s_add_i32 %[t0], %[gap], 1\n\t" \
-            "s_min_u32 %[t0], %[t0], 63\n\t" \
+            "s_min_u32 %[t0], %[t0], %[NT]\n\t" \
             "s_bfm_b64 %[m], %[t0], 0\n\t" \
             "s_and_b64 %[m], %[m], %[seed]\n\t" LZ_NC_NOSEED
         // the null event: the machine's state after it (see PairMachine::run)
@@ -881,6 +888,12 @@ struct DevWave {
             "s_mov_b32 %[atm], 0\n\t"
             "s_mov_b32 %[atl], 0\n\t"
             "s_mov_b32 %[atc], 0\n\t"
+            // the window positions of a round's third load: 64 + lane up to the window's last, then the positions from 0 on
+            // again (their bits are set already, and no two lanes of one LDS atomic meet on a word more often than k-mers do)
+            "v_add_u32_e32 %[w1], 64, %[lane]\n\t"
+            "v_subrev_u32_e32 %[dumv], %[WIN], %[w1]\n\t"
+            "v_min_u32_e32 %[w1], %[w1], %[dumv]\n\t"
+            "v_add_u32_e32 %[dumv], %[wdum], %[lane]\n\t"  // a lane's own word behind the bitmap
             "s_nop 3\n"
             "Lnc_top_%=:\n\t"
             // the queue head: candidates the last match has passed go
@@ -901,7 +914,7 @@ struct DevWave {
             "s_cbranch_scc1 Lnc_end_%=\n\t"
             "s_cmp_gt_i32 %[rend], %[rlim]\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"
-            LZ_NC_LOADS
+            LZ_NC_LOADS_F
             // While the loads fly: the next queued candidate and, should the round find no seed candidate, whether it is
             // a null event (t2 = 1): plain, distant, the open region short (dropped), both extensions empty by the record
             "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
@@ -964,12 +977,12 @@ struct DevWave {
             "Lnc_ok_%=:\n\t"
             "s_mov_b32 %[t2], 1\n"
             "Lnc_chk_%=:\n\t"
-            LZ_NC_ROUND
+            LZ_NC_ROUND_F
             "s_mov_b32 %[code], 1\n\t"
             LZ_NC_SEEDS
-            "s_cbranch_scc1 Lnc_seedev_%=\n\t"              // a seed candidate: the round is done; the event itself, if it is simple
+            "s_cbranch_scc1 Lnc_fseed_%=\n\t"               // a seed candidate: the round is done; the event itself, if it is simple
             "s_cmp_lt_i32 %[blen], 1\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the candidate is not plain: likewise
+            "s_cbranch_scc1 Lnc_npl_%=\n\t"                 // the candidate is not plain: likewise
             "s_mov_b32 %[code], 2\n\t"
             "s_cmp_eq_u32 %[t2], 0\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the event is found but is not a null event
@@ -1003,31 +1016,29 @@ struct DevWave {
             // what the general turn and the seed event need besides -- prs, plit, pre, the open region -- is a function of
             // the last committed entry and of fok = prs - plit, the same for every null event over a dropped region, and is
             // rebuilt when the run ends, Lnc_frec)
-            "s_sub_i32 %[fok], %[prs], %[plit]\n"
+            "s_sub_i32 %[fok], %[prs], %[plit]\n\t"
+            "s_sub_i32 %[t2], %[qh], 1\n"                  // the last committed entry (t2 stays untouched to the end of the turn)
             "Lnc_fturn_%=:\n\t"
-            "s_sub_i32 %[t2], %[qh], 1\n\t"                // the last committed entry (t2 stays untouched to the end of the turn)
             "v_readlane_b32 %[cls], %[alen], %[t2]\n\t"
             "s_bitcmp0_b32 %[cls], 15\n\t"
-            "s_cbranch_scc1 Lnc_frec_%=\n\t"
+            "s_cbranch_scc1 Lnc_fnogo_%=\n\t"
             "s_bfe_u32 %[qh], %[cls], 0x70008\n\t"          // the successor (the entries between are passed)
-            LZ_NC_LOADS
-            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
+            LZ_NC_LOADS_F
+            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"   // (its word: bits 17..24 = the match and its forward extension)
             "v_readlane_b32 %[ap], %[apos], %[qh]\n\t"
             "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
-            "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
-            "s_sext_i32_i8 %[blen], %[blen]\n\t"
             "s_sub_i32 %[gap], %[ap], %[i]\n\t"
-            LZ_NC_ROUND
-            "s_nop 0\n\t"
+            LZ_NC_ROUND_F
             LZ_NC_SEEDS
             "s_cbranch_scc1 Lnc_frec_%=\n\t"               // a seed candidate: the state first, then the seed event
-            "s_bfe_u32 %[t0], %[rec], 0x50018\n\t"          // e
-            "s_add_i32 %[t0], %[t0], %[blen]\n\t"
+            "s_bfe_u32 %[t0], %[blen], 0x80011\n\t"
             "s_add_i32 %[i], %[ap], %[t0]\n\t"
             "s_add_i32 %[rend], %[bpos], %[t0]\n\t"
-            "s_add_i32 %[qh], %[qh], 1\n\t"
+            "s_mov_b32 %[t2], %[qh]\n\t"
             LZ_NC_COUNT
             "s_branch Lnc_fturn_%=\n"
+            "Lnc_fnogo_%=:\n\t"                            // the run ends behind entry t2
+            "s_add_i32 %[qh], %[t2], 1\n"
             // the machine's state after the null event of entry t2 (see LZ_NC_COMMIT): avail = apos - fok
             "Lnc_frec_%=:\n\t"
             "v_readlane_b32 %[t0], %[apos], %[t2]\n\t"
@@ -1050,7 +1061,8 @@ struct DevWave {
             "s_bitcmp0_b32 %[cls], 15\n\t"
             "s_cbranch_scc1 Lnc_top_%=\n"                   // the run ended at an entry that is not GO: the general turn
             "Lnc_fseed_%=:\n\t"                             // a seed candidate: as above (the queue head is the successor)
-            "s_mov_b32 %[code], 1\n"
+            "s_mov_b32 %[code], 1\n\t"
+            LZ_NC_FIX
             // The seed event (code = 1 here; every way out before the last line leaves it so, and seed / rk0 / rk1 / qk
             // untouched: find_event then does the same from the round).  The simple case is found here: the first step with
             // a seed candidate lies before the queued candidate's, ONE window position carries its msl-mer, the 64 symbols
@@ -1059,6 +1071,7 @@ struct DevWave {
             // (parser.cpp:548-580, 604-606) -- adv = the step, bpos, blen = msl + the matching symbols behind.
             "Lnc_seedev_%=:\n\t"
             "s_ff1_i32_b64 %[t0], %[m]\n\t"                 // l
+            LZ_NC_WHY(1)
             "s_cmp_eq_u32 %[t0], %[gap]\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the queued candidate's own step: arbitration
             "v_readlane_b32 %[t1], %[qk], %[t0]\n\t"        // the step's msl-mer
@@ -1078,6 +1091,7 @@ struct DevWave {
             "s_bcnt1_i32_b64 %[kb], vcc\n\t"
             "s_bcnt1_i32_b64 %[kc], %[m]\n\t"
             "s_add_i32 %[t2], %[kb], %[kc]\n\t"
+            LZ_NC_WHY(2)
             "s_cmp_lg_u32 %[t2], 1\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // several window positions: the longest, then the nearest (find_event)
             "s_ff1_i32_b64 %[t2], vcc\n\t"
@@ -1091,6 +1105,7 @@ struct DevWave {
             // with an N in it has qend far below zero); reference the same inside [0, L) or [rc0, rc0 + L), L = (rlim - 34) / 2
             // (rlim = 2 L + 3 mrd - msl + 1 - 80), rc0 = L + 2 mrd
             "s_sub_i32 %[t1], %[qend], 104\n\t"
+            LZ_NC_WHY(3)
             "s_cmp_gt_i32 %[cls], %[t1]\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"
             "s_sub_i32 %[t1], %[rlim], 34\n\t"
@@ -1126,12 +1141,14 @@ struct DevWave {
             "v_and_b32_e32 %[aq], 3, %[aq]\n\t"
             "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t"
             "s_nop 0\n\t"
+            LZ_NC_WHY(4)
             "s_cmp_eq_u64 %[m], 0\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // 64 more symbols match: the general path measures on
             "s_ff1_i32_b64 %[blen], %[m]\n\t"
             "s_add_i32 %[blen], %[blen], 7\n\t"
             "s_mov_b32 %[ap], %[t0]\n\t"
             "s_mov_b32 %[bpos], %[rec]\n\t"
+            LZ_NC_WHY(5)
             "s_mov_b32 %[code], 4\n\t"                      // from here on the event is known: any way out hands it to the machine
             // The close match itself (PairMachine::run: gap_fill, match_run, the first chunk of extend_forward), when every
             // symbol it looks at is a real symbol of one strand and the forward extension breaks inside its first chunk.
@@ -1326,6 +1343,8 @@ struct DevWave {
             "s_cmp_le_i32 %[t1], %[MRD]\n\t"
             "s_cbranch_scc1 Lnc_chk_%=\n\t"
             "s_branch Lnc_distant_%=\n"
+            "Lnc_npl_%=:\n\t"
+            LZ_NC_FIX
             "Lnc_end_%=:\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_nop 4"
@@ -1333,15 +1352,16 @@ struct DevWave {
               [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec),
               [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [m] "=&s"(m), [seed] "=&s"(seed),
               [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc), [m2] "=&s"(m2),
-              [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq)
+              [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), [w1] "=&v"(w1), [dumv] "=&v"(dumv)
             : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [ocl] "s"(ocl_u), [oclit] "s"(oclit_u),
-              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend),
-              [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), [scrw] "v"(scrw),
+              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS), [wzero] "s"((int)SEED_BM_WORDS + 64),
+              [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane),
               [ldsb] "v"(ldsb), [zero] "v"(zero),
-              [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [W1] "n"(WIN - 1), [NR1] "n"(WIN - 64)
+              [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64)
             : "vcc", "scc", "memory");
-#undef LZ_NC_LOADS
-#undef LZ_NC_ROUND
+#undef LZ_NC_LOADS_F
+#undef LZ_NC_ROUND_F
+#undef LZ_NC_FIX
 #undef LZ_NC_SEEDS
 #undef LZ_NC_COMMIT
         q_head = qh;
@@ -1365,6 +1385,10 @@ struct DevWave {
             const bool nofwd = !((u32)rec & EXT_REC_FWDK);
             sr[0] += close; sr[1] += !close && kept; sr[2] += !close && !kept && nofwd; sr[3] += !close && !kept && !nofwd;
         }
+        if (code == 1 && seed != 0) {         // why the loop's seed event handed the round back
+            sw[0] += why == 1; sw[1] += why == 2 && kb + kc == 0; sw[2] += why == 2 && kb + kc > 1; sw[3] += why == 3; sw[4] += why == 4; sw[5] += why == 0;
+        }
+        if (code == 4) sw[6] += 1;            // the event known, its commit left to the machine
 #endif
         return code;
     }
@@ -1721,6 +1745,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[k], lane == 0 ? (unsigned long long)w.st[k] : 0ULL);
     for (int k = 0; k < 4; ++k) atomicAdd(&g_chain_stats[8 + k], lane == 0 ? w.stc[k] : 0ULL);
     for (int k = 0; k < 4; ++k) atomicAdd(&g_chain_stats[12 + k], lane == 0 ? (unsigned long long)w.sr[k] : 0ULL);
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[16 + k], lane == 0 ? (unsigned long long)w.sw[k] : 0ULL);
 #endif
 #ifdef LZANI_STAMPS
     w.stamp(0);
@@ -1755,7 +1780,7 @@ __global__ void __launch_bounds__(256, LZANI_WAVES_PER_SIMD) k_pairs(PairArgs a)
     const int lane = threadIdx.x & 63;
     __shared__ u32 s_seed[4][SEED_LDS_WORDS];
     u32* const lds = s_seed[threadIdx.x >> 6];
-    for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[k] = 0;
+    for (int k = lane; k < SEED_LDS_WORDS; k += 64) lds[k] = 0;
     u32 qx = xcc_id() % NQUEUES, dry = 0;
     for (;;) {
         // One ticket per wave.  NB: this is the only lane-dependent branch of the persistent loop.
@@ -1797,7 +1822,7 @@ __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32
     u32* const lds = s_dyn + (threadIdx.x >> 6) * SEED_LDS_WORDS;
     u32* const flt = s_dyn + BLK_WAVES * SEED_LDS_WORDS;
     u32* const ctl = s_dyn;                        // three words of wave 0's seed bitmap while the block is between segments (zeroed before wave 0 goes on)
-    for (int k = lane; k < SEED_BM_WORDS; k += 64) lds[k] = 0;
+    for (int k = lane; k < SEED_LDS_WORDS; k += 64) lds[k] = 0;
     u32 qx = xcc_id() % NQUEUES, dry = 0, have_slot = 0xFFFFFFFFu;
     for (;;) {
         __syncthreads();                           // (ctl is free: nobody is inside a pair)
