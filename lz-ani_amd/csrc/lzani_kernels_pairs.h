@@ -888,6 +888,7 @@ struct DevWave {
             "s_mov_b32 %[atm], 0\n\t"
             "s_mov_b32 %[atl], 0\n\t"
             "s_mov_b32 %[atc], 0\n\t"
+            "s_mov_b64 %[m2], -1\n\t"                      // (0 = the seed candidates of the turn that follows are known to be false, Lnc_snone)
             // the window positions of a round's third load: 64 + lane up to the window's last, then the positions from 0 on
             // again (their bits are set already, and no two lanes of one LDS atomic meet on a word more often than k-mers do)
             "v_add_u32_e32 %[w1], 64, %[lane]\n\t"
@@ -922,6 +923,7 @@ struct DevWave {
             "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
             "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
             "s_mov_b32 %[t2], 0\n\t"
+            "s_mov_b32 %[cls], 0\n\t"                        // (1 = the open region is kept, or there is none; bit 15 = a fast turn, Lnc_snone)
             "s_bfe_u32 %[code], %[blen], 0x10010\n\t"       // chain_classes' bit 16: plain, both extensions in the record, aw symbols into both texts
             "s_sext_i32_i8 %[blen], %[blen]\n\t"            // (the rest of the word is chain_classes')
             "s_sub_i32 %[gap], %[ap], %[i]\n\t"
@@ -930,7 +932,6 @@ struct DevWave {
             "s_cmp_le_i32 %[gap], %[MQD]\n\t"
             "s_cbranch_scc1 Lnc_close_%=\n"
             "Lnc_distant_%=:\n\t"
-            "s_mov_b32 %[cls], 0\n\t"                        // (1 = the open region is kept, or there is none)
             "s_cmp_lt_i32 %[prs], 0\n\t"
             "s_cbranch_scc1 Lnc_kept_%=\n\t"
             "s_sub_i32 %[t1], %[pre], %[prs]\n\t"
@@ -980,7 +981,8 @@ struct DevWave {
             LZ_NC_ROUND_F
             "s_mov_b32 %[code], 1\n\t"
             LZ_NC_SEEDS
-            "s_cbranch_scc1 Lnc_fseed_%=\n\t"               // a seed candidate: the round is done; the event itself, if it is simple
+            "s_cbranch_scc1 Lnc_sseed_%=\n"                 // a seed candidate: the round is done; the event itself, if it is simple
+            "Lnc_noseed_%=:\n\t"
             "s_cmp_lt_i32 %[blen], 1\n\t"
             "s_cbranch_scc1 Lnc_npl_%=\n\t"                 // the candidate is not plain: likewise
             "s_mov_b32 %[code], 2\n\t"
@@ -1030,7 +1032,8 @@ struct DevWave {
             "s_sub_i32 %[gap], %[ap], %[i]\n\t"
             LZ_NC_ROUND_F
             LZ_NC_SEEDS
-            "s_cbranch_scc1 Lnc_frec_%=\n\t"               // a seed candidate: the state first, then the seed event
+            "s_cbranch_scc1 Lnc_frec_%=\n"                  // a seed candidate: the state first, then the seed event
+            "Lnc_fcont_%=:\n\t"
             "s_bfe_u32 %[t0], %[blen], 0x80011\n\t"
             "s_add_i32 %[i], %[ap], %[t0]\n\t"
             "s_add_i32 %[rend], %[bpos], %[t0]\n\t"
@@ -1070,7 +1073,8 @@ struct DevWave {
             // that is the event -- a seed is at least msl long and no anchor stands at its step to arbitrate with
             // (parser.cpp:548-580, 604-606) -- adv = the step, bpos, blen = msl + the matching symbols behind.
             "Lnc_seedev_%=:\n\t"
-            "s_ff1_i32_b64 %[t0], %[m]\n\t"                 // l
+            "s_ff1_i32_b64 %[t0], %[m]\n"                   // l
+            "Lnc_sdl_%=:\n\t"
             LZ_NC_WHY(1)
             "s_cmp_eq_u32 %[t0], %[gap]\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the queued candidate's own step: arbitration
@@ -1079,26 +1083,26 @@ struct DevWave {
             "s_sub_i32 %[kc], %[t2], 64\n\t"
             "s_max_i32 %[kc], %[kc], 0\n\t"
             "s_min_u32 %[kb], %[t2], 64\n\t"
-            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk0]\n\t"
-            "v_cmp_eq_u32_e64 %[m], %[t1], %[rk1]\n\t"
+            "s_sub_i32 %[kb], 64, %[kb]\n\t"                // (the positions of the first load beyond it leave by a shift)
+            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk1]\n\t"
             "s_bfm_b64 %[m2], %[kc], 0\n\t"
-            "s_and_b64 %[m], %[m], %[m2]\n\t"
-            "s_cmp_eq_u32 %[kb], 64\n\t"
-            "s_cbranch_scc1 Lnc_sd1_%=\n\t"
-            "s_bfm_b64 %[m2], %[kb], 0\n\t"
-            "s_and_b64 vcc, vcc, %[m2]\n"
-            "Lnc_sd1_%=:\n\t"
-            "s_bcnt1_i32_b64 %[kb], vcc\n\t"
-            "s_bcnt1_i32_b64 %[kc], %[m]\n\t"
-            "s_add_i32 %[t2], %[kb], %[kc]\n\t"
+            "s_and_b64 %[m2], %[m2], vcc\n\t"
+            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk0]\n\t"
+            "s_bcnt1_i32_b64 %[kc], %[m2]\n\t"
+            "s_lshl_b64 vcc, vcc, %[kb]\n\t"
+            "s_bcnt1_i32_b64 %[t1], vcc\n\t"
+            "s_add_i32 %[t2], %[t1], %[kc]\n\t"
             LZ_NC_WHY(2)
+            "s_cmp_eq_u32 %[t2], 0\n\t"
+            "s_cbranch_scc1 Lnc_sfalse_%=\n\t"              // no window position: the prefilter's false candidate (the bitmap holds all 80 positions)
             "s_cmp_lg_u32 %[t2], 1\n\t"
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 // several window positions: the longest, then the nearest (find_event)
             "s_ff1_i32_b64 %[t2], vcc\n\t"
-            "s_ff1_i32_b64 %[t1], %[m]\n\t"
-            "s_add_i32 %[t1], %[t1], 64\n\t"
-            "s_cmp_lg_u32 %[kb], 0\n\t"
-            "s_cselect_b32 %[t2], %[t2], %[t1]\n\t"         // idx
+            "s_sub_i32 %[t2], %[t2], %[kb]\n\t"
+            "s_ff1_i32_b64 %[kc], %[m2]\n\t"
+            "s_add_i32 %[kc], %[kc], 64\n\t"
+            "s_cmp_lg_u32 %[t1], 0\n\t"
+            "s_cselect_b32 %[t2], %[t2], %[kc]\n\t"         // idx
             "s_add_i32 %[rec], %[rend], %[t2]\n\t"          // the seed in the reference ...
             "s_add_i32 %[cls], %[i], %[t0]\n\t"             // ... and in the query
             // bounds: query [cls + 7, cls + 71) inside [0, Lq), Lq = qend - 33 (qend = the scan's end D - msl = Lq + mrd - msl; a pair
@@ -1330,8 +1334,29 @@ struct DevWave {
             "s_add_i32 %[rend], %[fok], %[kb]\n\t"
             "s_mov_b32 %[pre], %[i]\n\t"
             "s_mov_b32 %[code], 0\n\t"
+            "s_mov_b64 %[m2], -1\n\t"
             LZ_NC_COUNT
             "s_branch Lnc_top_%=\n"
+            // a false seed candidate (nine in ten of the rounds that have one): the next one; none left = the round has no seed
+            // candidate after all -- the fast turn goes on where it stood, the general turn is taken again with the flag set
+            "Lnc_sfalse_%=:\n\t"
+            "s_bitset0_b64 %[m], %[t0]\n\t"
+            "s_cmp_eq_u64 %[m], 0\n\t"
+            "s_cbranch_scc1 Lnc_snone_%=\n\t"
+            "s_ff1_i32_b64 %[t0], %[m]\n\t"
+            "s_branch Lnc_sdl_%=\n"
+            "Lnc_snone_%=:\n\t"
+            "s_mov_b32 %[code], 0\n\t"
+            "s_mov_b64 %[m2], -1\n\t"
+            "s_bitcmp1_b32 %[cls], 15\n\t"
+            "s_cbranch_scc1 Lnc_fcont_%=\n\t"
+            "s_mov_b64 %[m2], 0\n\t"
+            "s_branch Lnc_top_%=\n"
+            "Lnc_sseed_%=:\n\t"                            // the general turn's seed candidates: known to be false if this is that second pass
+            "s_cmp_eq_u64 %[m2], 0\n\t"
+            "s_mov_b64 %[m2], -1\n\t"
+            "s_cbranch_scc1 Lnc_noseed_%=\n\t"
+            "s_branch Lnc_fseed_%=\n"
             "Lnc_kept_%=:\n\t"                              // no region to drop: the candidate may look back over the literals since
             "s_mov_b32 %[cls], 1\n\t"                        // the last match only (avail = lit), the rest is the same
             "s_mov_b32 %[t1], %[gap]\n\t"
@@ -1386,7 +1411,7 @@ struct DevWave {
             sr[0] += close; sr[1] += !close && kept; sr[2] += !close && !kept && nofwd; sr[3] += !close && !kept && !nofwd;
         }
         if (code == 1 && seed != 0) {         // why the loop's seed event handed the round back
-            sw[0] += why == 1; sw[1] += why == 2 && kb + kc == 0; sw[2] += why == 2 && kb + kc > 1; sw[3] += why == 3; sw[4] += why == 4; sw[5] += why == 0;
+            sw[0] += why == 1; sw[2] += why == 2; sw[3] += why == 3; sw[4] += why == 4; sw[5] += why == 0;
         }
         if (code == 4) sw[6] += 1;            // the event known, its commit left to the machine
 #endif
