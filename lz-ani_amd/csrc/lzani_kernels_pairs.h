@@ -774,7 +774,7 @@ struct DevWave {
         const int ilim = imin(scan_pos, iend) - NT;             // the queue and the query cover the tracking steps of i <= ilim
         const int rlim = R.len - MSL + 1 - WIN;                 // the seed window of r_end <= rlim is complete
         const u32 ldsb = (u32)(size_t)bitmap;                   // LDS byte offset (low half of the flat address)
-        const u32 zero = 0;
+        const u32 zero = 0, one = 1;
         const u32* const qks = uniform_ptr(qkS);
         const u32* const rks = uniform_ptr(rkS);
         int code, ap, rec, t0, t1, t2, kb, kc, qh = q_head;
@@ -807,6 +807,16 @@ struct DevWave {
         // the three loads of a tracking round (msl-mers of the 41 steps and of the 80 window positions).  The lanes beyond
         // (steps >= NT, window positions >= WIN) are not masked: their steps are cut from the result (LZ_NC_SEEDS), their
         // window positions are positions of the first load again; what leaves the loop with the round in hand is masked then (LZ_NC_FIX)
+#ifdef LZANI_EXP_CACHED                             // diagnostic build (wrong results): the window k-mers from one cached place
+#define LZ_NC_LOADS_F \
+            "s_and_b32 %[t0], %[rend], 0x3ff\n\t" \
+            "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t" \
+            "v_add_lshl_u32 %[a1], %[lane], %[t0], 2\n\t" \
+            "v_add_lshl_u32 %[aq], %[w1], %[t0], 2\n\t" \
+            "global_load_dword %[qk], %[a0], %[qks]\n\t" \
+            "global_load_dword %[rk0], %[a1], %[rks]\n\t" \
+            "global_load_dword %[rk1], %[aq], %[rks]\n\t"
+#else
 #define LZ_NC_LOADS_F \
             "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t" \
             "v_add_lshl_u32 %[a1], %[lane], %[rend], 2\n\t" \
@@ -814,6 +824,7 @@ struct DevWave {
             "global_load_dword %[qk], %[a0], %[qks]\n\t" \
             "global_load_dword %[rk0], %[a1], %[rks]\n\t" \
             "global_load_dword %[rk1], %[aq], %[rks]\n\t"
+#endif
         // the round itself (track_round + seed_prefilter): window k-mers into the LDS bitmap, every step tests its own, the
         // bits are cleared again; leaves the steps with a seed candidate in seed.  A lane without a k-mer (KM_INVALID >> 5 is
         // beyond every word of the bitmap) writes to the first word behind the bitmap and reads the second one, which stays
@@ -821,18 +832,18 @@ struct DevWave {
 #define LZ_NC_ROUND_F \
             "s_waitcnt vmcnt(0)\n\t" \
             "v_lshrrev_b32_e32 %[a0], 5, %[rk0]\n\t" \
-            "v_lshlrev_b32_e64 %[t], %[rk0], 1\n\t" \
+            "v_lshlrev_b32_e32 %[t], %[rk0], %[one]\n\t" \
             "v_min_u32_e32 %[a0], %[dumv], %[a0]\n\t" \
             "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t" \
             "ds_or_b32 %[a0], %[t]\n\t" \
             "v_lshrrev_b32_e32 %[a1], 5, %[rk1]\n\t" \
-            "v_lshlrev_b32_e64 %[bq], %[rk1], 1\n\t" \
+            "v_lshlrev_b32_e32 %[bq], %[rk1], %[one]\n\t" \
             "v_min_u32_e32 %[a1], %[dumv], %[a1]\n\t" \
             "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t" \
             "ds_or_b32 %[a1], %[bq]\n\t" \
             "v_lshrrev_b32_e32 %[aq], 5, %[qk]\n\t" \
-            "v_lshlrev_b32_e64 %[t], %[qk], 1\n\t" \
-            "v_min_u32_e32 %[aq], %[wzero], %[aq]\n\t" \
+            "v_lshlrev_b32_e32 %[t], %[qk], %[one]\n\t" \
+            "v_min_u32_e32 %[aq], %[dumv], %[aq]\n\t" \
             "v_lshl_add_u32 %[aq], %[aq], 2, %[ldsb]\n\t" \
             "ds_read_b32 %[aq], %[aq]\n\t" \
             "ds_write_b32 %[a0], %[zero]\n\t" \
@@ -848,7 +859,10 @@ struct DevWave {
             "v_cmp_gt_u32_e32 vcc, %[NT], %[lane]\n\t" \
             "s_nop 1\n\t" \
             "v_cndmask_b32_e64 %[rk1], -1, %[rk1], %[m2]\n\t" \
-            "v_cndmask_b32_e32 %[qk], -1, %[qk], vcc\n"
+            "v_cndmask_b32_e32 %[qk], -1, %[qk], vcc\n\t" \
+            "v_cmp_ne_u32_e32 vcc, -1, %[qk]\n\t"          /* (a step without a k-mer has read its own word behind the bitmap) */ \
+            "s_and_b64 %[seed], %[seed], vcc\n\t" \
+            "s_and_b64 %[m], %[m], vcc\n"
         // a seed candidate matters only up to the step of the queued candidate itself (gap steps ahead): m = the steps
         // with a seed candidate among them (scc = any); seed keeps them all for find_event
 #define LZ_NC_SEEDS \
@@ -1019,27 +1033,40 @@ struct DevWave {
             // the last committed entry and of fok = prs - plit, the same for every null event over a dropped region, and is
             // rebuilt when the run ends, Lnc_frec)
             "s_sub_i32 %[fok], %[prs], %[plit]\n\t"
-            "s_sub_i32 %[t2], %[qh], 1\n"                  // the last committed entry (t2 stays untouched to the end of the turn)
-            "Lnc_fturn_%=:\n\t"
-            "v_readlane_b32 %[cls], %[alen], %[t2]\n\t"
-            "s_bitcmp0_b32 %[cls], 15\n\t"
-            "s_cbranch_scc1 Lnc_fnogo_%=\n\t"
-            "s_bfe_u32 %[qh], %[cls], 0x70008\n\t"          // the successor (the entries between are passed)
-            LZ_NC_LOADS_F
-            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"   // (its word: bits 17..24 = the match and its forward extension)
-            "v_readlane_b32 %[ap], %[apos], %[qh]\n\t"
-            "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
-            "s_sub_i32 %[gap], %[ap], %[i]\n\t"
-            LZ_NC_ROUND_F
-            LZ_NC_SEEDS
-            "s_cbranch_scc1 Lnc_frec_%=\n"                  // a seed candidate: the state first, then the seed event
-            "Lnc_fcont_%=:\n\t"
-            "s_bfe_u32 %[t0], %[blen], 0x80011\n\t"
-            "s_add_i32 %[i], %[ap], %[t0]\n\t"
-            "s_add_i32 %[rend], %[bpos], %[t0]\n\t"
-            "s_mov_b32 %[t2], %[qh]\n\t"
+            "s_sub_i32 %[t2], %[qh], 1\n\t"                // the last committed entry (t2 stays untouched to the end of the turn)
+            "v_readlane_b32 %[cls], %[alen], %[t2]\n"      // its word
+            // (two turns a pass: the successor's word, read for its length, is the committed entry's word of the next turn --
+            // the two registers take turns; what leaves the second turn puts them back: cls the committed entry's, blen the successor's)
+#define LZ_NC_FTURN(P, N, SFX) \
+            "Lnc_fturn" SFX "_%=:\n\t" \
+            "s_bitcmp0_b32 %[" P "], 15\n\t" \
+            "s_cbranch_scc1 Lnc_fnogo" SFX "_%=\n\t" \
+            "s_bfe_u32 %[qh], %[" P "], 0x70008\n\t"        /* the successor (the entries between are passed) */ \
+            LZ_NC_LOADS_F \
+            "v_readlane_b32 %[" N "], %[alen], %[qh]\n\t"   /* (its word: bits 17..24 = the match and its forward extension) */ \
+            "v_readlane_b32 %[ap], %[apos], %[qh]\n\t" \
+            "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t" \
+            "s_sub_i32 %[gap], %[ap], %[i]\n\t" \
+            LZ_NC_ROUND_F \
+            LZ_NC_SEEDS \
+            "s_cbranch_scc1 Lnc_frec" SFX "_%=\n"           /* a seed candidate: the state first, then the seed event */ \
+            "Lnc_fcont" SFX "_%=:\n\t" \
+            "s_bfe_u32 %[t0], %[" N "], 0x80011\n\t" \
+            "s_add_i32 %[i], %[ap], %[t0]\n\t" \
+            "s_add_i32 %[rend], %[bpos], %[t0]\n\t" \
+            "s_mov_b32 %[t2], %[qh]\n\t" \
             LZ_NC_COUNT
+            LZ_NC_FTURN("cls", "blen", "")
+            LZ_NC_FTURN("blen", "cls", "2")
             "s_branch Lnc_fturn_%=\n"
+            "Lnc_fnogo2_%=:\n\t"
+            "s_mov_b32 %[cls], %[blen]\n\t"
+            "s_branch Lnc_fnogo_%=\n"
+            "Lnc_frec2_%=:\n\t"
+            "s_mov_b32 %[t0], %[cls]\n\t"
+            "s_mov_b32 %[cls], %[blen]\n\t"
+            "s_mov_b32 %[blen], %[t0]\n\t"
+            "s_branch Lnc_frec_%=\n"
             "Lnc_fnogo_%=:\n\t"                            // the run ends behind entry t2
             "s_add_i32 %[qh], %[t2], 1\n"
             // the machine's state after the null event of entry t2 (see LZ_NC_COMMIT): avail = apos - fok
@@ -1066,6 +1093,8 @@ struct DevWave {
             "Lnc_fseed_%=:\n\t"                             // a seed candidate: as above (the queue head is the successor)
             "s_mov_b32 %[code], 1\n\t"
             LZ_NC_FIX
+            "s_cmp_eq_u64 %[m], 0\n\t"                      // (only steps without a k-mer)
+            "s_cbranch_scc1 Lnc_snone_%=\n"
             // The seed event (code = 1 here; every way out before the last line leaves it so, and seed / rk0 / rk1 / qk
             // untouched: find_event then does the same from the round).  The simple case is found here: the first step with
             // a seed candidate lies before the queued candidate's, ONE window position carries its msl-mer, the 64 symbols
@@ -1379,13 +1408,14 @@ struct DevWave {
               [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc), [m2] "=&s"(m2),
               [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), [w1] "=&v"(w1), [dumv] "=&v"(dumv)
             : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [ocl] "s"(ocl_u), [oclit] "s"(oclit_u),
-              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS), [wzero] "s"((int)SEED_BM_WORDS + 64),
+              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS),
               [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane),
-              [ldsb] "v"(ldsb), [zero] "v"(zero),
+              [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one),
               [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64)
             : "vcc", "scc", "memory");
 #undef LZ_NC_LOADS_F
 #undef LZ_NC_ROUND_F
+#undef LZ_NC_FTURN
 #undef LZ_NC_FIX
 #undef LZ_NC_SEEDS
 #undef LZ_NC_COMMIT

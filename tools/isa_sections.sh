@@ -15,7 +15,7 @@ c=re.sub(r'\bw\.stamp\((\d)\);', lambda m: 'LZMARK(%s);' % m.group(1), c)
 c=c.replace('namespace lzani {\n\ntypedef uint64_t u64;','#if defined(__HIP_DEVICE_COMPILE__)\n#define LZMARK(k) asm volatile("; LZMARK " #k)\n#else\n#define LZMARK(k)\n#endif\nnamespace lzani {\n\ntypedef uint64_t u64;',1)
 open('/tmp/lzani_core.h','w').write(c)
 PY
-cp csrc/lzani_layout.h csrc/lzani_kernels_index.h csrc/lzani_multi.h /tmp/
+cp csrc/lzani_layout.h csrc/lzani_kernels_index.h csrc/lzani_kernels_cand.h csrc/lzani_multi.h /tmp/
 cd /tmp && rm -f mark-hip-* && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-value -save-temps -o /tmp/mark.so /tmp/mark.hip -lrccl 2>/dev/null
 S=$(ls /tmp/mark-hip-amdgcn*gfx950*.s | head -1)
 awk "/^_ZN5lzani7${K}.*:/,/\.end_amdhsa_kernel/" $S > /tmp/kmark.s
