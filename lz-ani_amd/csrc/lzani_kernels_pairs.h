@@ -787,7 +787,7 @@ struct DevWave {
 #else
         const int qc_u = q_cnt, ilim_u = ilim, rlim_u = rlim;
 #endif
-        u32 rk0, rk1, qk, a0, a1, aq, t, bq, w1, dumv;
+        u32 rk0, rk1, qk, a0, a1, aq, t, bq, w1, dumv, qkb, rk0b, rk1b;
 #ifdef LZANI_CHAIN_STATS
         int ncnt = 0;
 #define LZ_NC_COUNT "s_add_i32 %[ncnt], %[ncnt], 1\n\t"
@@ -807,42 +807,32 @@ struct DevWave {
         // the three loads of a tracking round (msl-mers of the 41 steps and of the 80 window positions).  The lanes beyond
         // (steps >= NT, window positions >= WIN) are not masked: their steps are cut from the result (LZ_NC_SEEDS), their
         // window positions are positions of the first load again; what leaves the loop with the round in hand is masked then (LZ_NC_FIX)
-#ifdef LZANI_EXP_CACHED                             // diagnostic build (wrong results): the window k-mers from one cached place
-#define LZ_NC_LOADS_F \
-            "s_and_b32 %[t0], %[rend], 0x3ff\n\t" \
-            "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t" \
-            "v_add_lshl_u32 %[a1], %[lane], %[t0], 2\n\t" \
-            "v_add_lshl_u32 %[aq], %[w1], %[t0], 2\n\t" \
-            "global_load_dword %[qk], %[a0], %[qks]\n\t" \
-            "global_load_dword %[rk0], %[a1], %[rks]\n\t" \
-            "global_load_dword %[rk1], %[aq], %[rks]\n\t"
-#else
-#define LZ_NC_LOADS_F \
-            "v_add_lshl_u32 %[a0], %[lane], %[i], 2\n\t" \
-            "v_add_lshl_u32 %[a1], %[lane], %[rend], 2\n\t" \
-            "v_add_lshl_u32 %[aq], %[w1], %[rend], 2\n\t" \
-            "global_load_dword %[qk], %[a0], %[qks]\n\t" \
-            "global_load_dword %[rk0], %[a1], %[rks]\n\t" \
-            "global_load_dword %[rk1], %[aq], %[rks]\n\t"
-#endif
+#define LZ_NC_LOADS_X(I, R, QK, K0, K1) \
+            "v_add_lshl_u32 %[a0], %[lane], %[" I "], 2\n\t" \
+            "v_add_lshl_u32 %[a1], %[lane], %[" R "], 2\n\t" \
+            "v_add_lshl_u32 %[aq], %[w1], %[" R "], 2\n\t" \
+            "global_load_dword %[" QK "], %[a0], %[qks]\n\t" \
+            "global_load_dword %[" K0 "], %[a1], %[rks]\n\t" \
+            "global_load_dword %[" K1 "], %[aq], %[rks]\n\t"
+#define LZ_NC_LOADS_F LZ_NC_LOADS_X("i", "rend", "qk", "rk0", "rk1")
         // the round itself (track_round + seed_prefilter): window k-mers into the LDS bitmap, every step tests its own, the
         // bits are cleared again; leaves the steps with a seed candidate in seed.  A lane without a k-mer (KM_INVALID >> 5 is
-        // beyond every word of the bitmap) writes to the first word behind the bitmap and reads the second one, which stays
-        // zero (SEED_PAD): no lane select, no mask
-#define LZ_NC_ROUND_F \
-            "s_waitcnt vmcnt(0)\n\t" \
-            "v_lshrrev_b32_e32 %[a0], 5, %[rk0]\n\t" \
-            "v_lshlrev_b32_e32 %[t], %[rk0], %[one]\n\t" \
+        // beyond every word of the bitmap) works on its own word behind the bitmap (SEED_PAD) by a minimum: no lane select,
+        // no mask (a step without a k-mer may see its own window position's bit there: LZ_NC_FIX)
+#define LZ_NC_ROUND_X(WAIT, QK, K0, K1) \
+            WAIT "\n\t" \
+            "v_lshrrev_b32_e32 %[a0], 5, %[" K0 "]\n\t" \
+            "v_lshlrev_b32_e32 %[t], %[" K0 "], %[one]\n\t" \
             "v_min_u32_e32 %[a0], %[dumv], %[a0]\n\t" \
             "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t" \
             "ds_or_b32 %[a0], %[t]\n\t" \
-            "v_lshrrev_b32_e32 %[a1], 5, %[rk1]\n\t" \
-            "v_lshlrev_b32_e32 %[bq], %[rk1], %[one]\n\t" \
+            "v_lshrrev_b32_e32 %[a1], 5, %[" K1 "]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], %[" K1 "], %[one]\n\t" \
             "v_min_u32_e32 %[a1], %[dumv], %[a1]\n\t" \
             "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t" \
             "ds_or_b32 %[a1], %[bq]\n\t" \
-            "v_lshrrev_b32_e32 %[aq], 5, %[qk]\n\t" \
-            "v_lshlrev_b32_e32 %[t], %[qk], %[one]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], 5, %[" QK "]\n\t" \
+            "v_lshlrev_b32_e32 %[t], %[" QK "], %[one]\n\t" \
             "v_min_u32_e32 %[aq], %[dumv], %[aq]\n\t" \
             "v_lshl_add_u32 %[aq], %[aq], 2, %[ldsb]\n\t" \
             "ds_read_b32 %[aq], %[aq]\n\t" \
@@ -851,6 +841,7 @@ struct DevWave {
             "s_waitcnt lgkmcnt(2)\n\t" \
             "v_and_b32_e32 %[aq], %[aq], %[t]\n\t" \
             "v_cmp_ne_u32_e64 %[seed], 0, %[aq]\n\t"
+#define LZ_NC_ROUND_F LZ_NC_ROUND_X("s_waitcnt vmcnt(0)", "qk", "rk0", "rk1")
         // the lane masks a round went without, for what leaves the loop with the round in hand (find_event, the seed event)
 #define LZ_NC_FIX \
             "s_bfm_b64 %[m2], %[NT], 0\n\t" \
@@ -1035,38 +1026,59 @@ struct DevWave {
             "s_sub_i32 %[fok], %[prs], %[plit]\n\t"
             "s_sub_i32 %[t2], %[qh], 1\n\t"                // the last committed entry (t2 stays untouched to the end of the turn)
             "v_readlane_b32 %[cls], %[alen], %[t2]\n"      // its word
-            // (two turns a pass: the successor's word, read for its length, is the committed entry's word of the next turn --
-            // the two registers take turns; what leaves the second turn puts them back: cls the committed entry's, blen the successor's)
-#define LZ_NC_FTURN(P, N, SFX) \
+            "Lnc_fstart_%=:\n\t"
+            LZ_NC_LOADS_F
+            // Two turns a pass, in two sets of registers that take turns: a turn requests the k-mers of the NEXT turn's round
+            // -- where that round stands follows from the successor's queue entry alone, not from this round's outcome --
+            // before it waits for its own, so the loads of one turn fly during the LDS phase of the turn before.  A turn that
+            // ends the run (no GO, a seed candidate) leaves the request behind; what leaves the second turn puts the
+            // registers back: cls the committed entry's word, blen the successor's, i / rend the round's, qk / rk0 / rk1 its k-mers.
+#define LZ_NC_FTURN(P, N, IC, IN, RN, CQ, C0, C1, NQ, N0, N1, SFX) \
             "Lnc_fturn" SFX "_%=:\n\t" \
             "s_bitcmp0_b32 %[" P "], 15\n\t" \
             "s_cbranch_scc1 Lnc_fnogo" SFX "_%=\n\t" \
             "s_bfe_u32 %[qh], %[" P "], 0x70008\n\t"        /* the successor (the entries between are passed) */ \
-            LZ_NC_LOADS_F \
             "v_readlane_b32 %[" N "], %[alen], %[qh]\n\t"   /* (its word: bits 17..24 = the match and its forward extension) */ \
             "v_readlane_b32 %[ap], %[apos], %[qh]\n\t" \
             "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t" \
-            "s_sub_i32 %[gap], %[ap], %[i]\n\t" \
-            LZ_NC_ROUND_F \
-            LZ_NC_SEEDS \
-            "s_cbranch_scc1 Lnc_frec" SFX "_%=\n"           /* a seed candidate: the state first, then the seed event */ \
-            "Lnc_fcont" SFX "_%=:\n\t" \
             "s_bfe_u32 %[t0], %[" N "], 0x80011\n\t" \
-            "s_add_i32 %[i], %[ap], %[t0]\n\t" \
-            "s_add_i32 %[rend], %[bpos], %[t0]\n\t" \
+            "s_sub_i32 %[gap], %[ap], %[" IC "]\n\t" \
+            "s_add_i32 %[" IN "], %[ap], %[t0]\n\t" \
+            "s_add_i32 %[" RN "], %[bpos], %[t0]\n\t" \
+            LZ_NC_LOADS_X(IN, RN, NQ, N0, N1) \
+            LZ_NC_ROUND_X("s_waitcnt vmcnt(3)", CQ, C0, C1) \
+            LZ_NC_SEEDS \
+            "s_cbranch_scc1 Lnc_frec" SFX "_%=\n\t"         /* a seed candidate: the state first, then the seed event */ \
             "s_mov_b32 %[t2], %[qh]\n\t" \
             LZ_NC_COUNT
-            LZ_NC_FTURN("cls", "blen", "")
-            LZ_NC_FTURN("blen", "cls", "2")
+            LZ_NC_FTURN("cls", "blen", "i", "t1", "kb", "qk", "rk0", "rk1", "qkb", "rk0b", "rk1b", "")
+            LZ_NC_FTURN("blen", "cls", "t1", "i", "rend", "qkb", "rk0b", "rk1b", "qk", "rk0", "rk1", "2")
             "s_branch Lnc_fturn_%=\n"
             "Lnc_fnogo2_%=:\n\t"
+            "s_mov_b32 %[i], %[t1]\n\t"
+            "s_mov_b32 %[rend], %[kb]\n\t"
             "s_mov_b32 %[cls], %[blen]\n\t"
             "s_branch Lnc_fnogo_%=\n"
             "Lnc_frec2_%=:\n\t"
+            "s_mov_b32 %[i], %[t1]\n\t"
+            "s_mov_b32 %[rend], %[kb]\n\t"
             "s_mov_b32 %[t0], %[cls]\n\t"
             "s_mov_b32 %[cls], %[blen]\n\t"
             "s_mov_b32 %[blen], %[t0]\n\t"
+            "s_waitcnt vmcnt(0)\n\t"                        // (the request left behind is for qk / rk0 / rk1)
+            "v_mov_b32_e32 %[qk], %[qkb]\n\t"
+            "v_mov_b32_e32 %[rk0], %[rk0b]\n\t"
+            "v_mov_b32_e32 %[rk1], %[rk1b]\n\t"
             "s_branch Lnc_frec_%=\n"
+            // back into the run behind a round whose seed candidates were all false (Lnc_snone): the successor's null event
+            "Lnc_fcont_%=:\n\t"
+            "s_bfe_u32 %[t0], %[blen], 0x80011\n\t"
+            "s_add_i32 %[i], %[ap], %[t0]\n\t"
+            "s_add_i32 %[rend], %[bpos], %[t0]\n\t"
+            "s_mov_b32 %[t2], %[qh]\n\t"
+            "s_mov_b32 %[cls], %[blen]\n\t"
+            LZ_NC_COUNT
+            "s_branch Lnc_fstart_%=\n"
             "Lnc_fnogo_%=:\n\t"                            // the run ends behind entry t2
             "s_add_i32 %[qh], %[t2], 1\n"
             // the machine's state after the null event of entry t2 (see LZ_NC_COMMIT): avail = apos - fok
@@ -1400,13 +1412,13 @@ struct DevWave {
             "Lnc_npl_%=:\n\t"
             LZ_NC_FIX
             "Lnc_end_%=:\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
             "s_nop 4"
             : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit),
               [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec),
               [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [m] "=&s"(m), [seed] "=&s"(seed),
               [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc), [m2] "=&s"(m2),
-              [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), [w1] "=&v"(w1), [dumv] "=&v"(dumv)
+              [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), [w1] "=&v"(w1), [dumv] "=&v"(dumv), [qkb] "=&v"(qkb), [rk0b] "=&v"(rk0b), [rk1b] "=&v"(rk1b)
             : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [ocl] "s"(ocl_u), [oclit] "s"(oclit_u),
               [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS),
               [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane),
@@ -1414,6 +1426,8 @@ struct DevWave {
               [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64)
             : "vcc", "scc", "memory");
 #undef LZ_NC_LOADS_F
+#undef LZ_NC_LOADS_X
+#undef LZ_NC_ROUND_X
 #undef LZ_NC_ROUND_F
 #undef LZ_NC_FTURN
 #undef LZ_NC_FIX
