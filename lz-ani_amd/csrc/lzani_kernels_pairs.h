@@ -807,6 +807,16 @@ struct DevWave {
         // the three loads of a tracking round (msl-mers of the 41 steps and of the 80 window positions).  The lanes beyond
         // (steps >= NT, window positions >= WIN) are not masked: their steps are cut from the result (LZ_NC_SEEDS), their
         // window positions are positions of the first load again; what leaves the loop with the round in hand is masked then (LZ_NC_FIX)
+#ifdef LZANI_EXP_CACHED                             // diagnostic build (wrong results): the window k-mers from one cached place
+#define LZ_NC_LOADS_X(I, R, QK, K0, K1) \
+            "s_and_b32 %[t0], %[" R "], 0x3ff\n\t" \
+            "v_add_lshl_u32 %[a0], %[lane], %[" I "], 2\n\t" \
+            "v_add_lshl_u32 %[a1], %[lane], %[t0], 2\n\t" \
+            "v_add_lshl_u32 %[aq], %[w1], %[t0], 2\n\t" \
+            "global_load_dword %[" QK "], %[a0], %[qks]\n\t" \
+            "global_load_dword %[" K0 "], %[a1], %[rks]\n\t" \
+            "global_load_dword %[" K1 "], %[aq], %[rks]\n\t"
+#else
 #define LZ_NC_LOADS_X(I, R, QK, K0, K1) \
             "v_add_lshl_u32 %[a0], %[lane], %[" I "], 2\n\t" \
             "v_add_lshl_u32 %[a1], %[lane], %[" R "], 2\n\t" \
@@ -814,11 +824,36 @@ struct DevWave {
             "global_load_dword %[" QK "], %[a0], %[qks]\n\t" \
             "global_load_dword %[" K0 "], %[a1], %[rks]\n\t" \
             "global_load_dword %[" K1 "], %[aq], %[rks]\n\t"
+#endif
 #define LZ_NC_LOADS_F LZ_NC_LOADS_X("i", "rend", "qk", "rk0", "rk1")
         // the round itself (track_round + seed_prefilter): window k-mers into the LDS bitmap, every step tests its own, the
         // bits are cleared again; leaves the steps with a seed candidate in seed.  A lane without a k-mer (KM_INVALID >> 5 is
         // beyond every word of the bitmap) works on its own word behind the bitmap (SEED_PAD) by a minimum: no lane select,
         // no mask (a step without a k-mer may see its own window position's bit there: LZ_NC_FIX)
+#ifdef LZANI_EXP_LDSLIN                             // diagnostic build (wrong results): every lane on its own LDS bank
+#define LZ_NC_ROUND_X(WAIT, QK, K0, K1) \
+            WAIT "\n\t" \
+            "v_and_b32_e32 %[a0], 31, %[lane]\n\t" \
+            "v_lshlrev_b32_e32 %[t], %[" K0 "], %[one]\n\t" \
+            "v_min_u32_e32 %[a0], %[dumv], %[a0]\n\t" \
+            "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t" \
+            "ds_or_b32 %[a0], %[t]\n\t" \
+            "v_and_b32_e32 %[a1], 31, %[lane]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], %[" K1 "], %[one]\n\t" \
+            "v_min_u32_e32 %[a1], %[dumv], %[a1]\n\t" \
+            "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t" \
+            "ds_or_b32 %[a1], %[bq]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], 5, %[" QK "]\n\t" \
+            "v_lshlrev_b32_e32 %[t], %[" QK "], %[one]\n\t" \
+            "v_min_u32_e32 %[aq], %[dumv], %[aq]\n\t" \
+            "v_lshl_add_u32 %[aq], %[lane], 2, %[ldsb]\n\t" \
+            "ds_read_b32 %[aq], %[aq]\n\t" \
+            "ds_write_b32 %[a0], %[zero]\n\t" \
+            "ds_write_b32 %[a1], %[zero]\n\t" \
+            "s_waitcnt lgkmcnt(2)\n\t" \
+            "v_and_b32_e32 %[aq], %[aq], %[t]\n\t" \
+            "v_cmp_ne_u32_e64 %[seed], 0, %[aq]\n\t"
+#else
 #define LZ_NC_ROUND_X(WAIT, QK, K0, K1) \
             WAIT "\n\t" \
             "v_lshrrev_b32_e32 %[a0], 5, %[" K0 "]\n\t" \
@@ -841,6 +876,7 @@ struct DevWave {
             "s_waitcnt lgkmcnt(2)\n\t" \
             "v_and_b32_e32 %[aq], %[aq], %[t]\n\t" \
             "v_cmp_ne_u32_e64 %[seed], 0, %[aq]\n\t"
+#endif
 #define LZ_NC_ROUND_F LZ_NC_ROUND_X("s_waitcnt vmcnt(0)", "qk", "rk0", "rk1")
         // the lane masks a round went without, for what leaves the loop with the round in hand (find_event, the seed event)
 #define LZ_NC_FIX \
@@ -1807,6 +1843,16 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
 #endif
 #if defined(LZANI_EXP) && LZANI_EXP == 3                      // diagnostic build: the join alone, no scan
     res[0] = res[1] = res[2] = 0;
+    if (!JOIN)
+#endif
+#ifdef LZANI_EXP_REFILLS                                      // diagnostic build: the refills of the pair alone (queue after queue), no scan
+    {
+        res[0] = res[1] = res[2] = 0;
+        if constexpr (JOIN) {
+            int guard = 0;
+            while (w.scan_pos < w.iend && ++guard < 100000) { w.refill(w.scan_pos); res[0] += w.q_cnt; }
+        }
+    }
     if (!JOIN)
 #endif
     m.run(res);
