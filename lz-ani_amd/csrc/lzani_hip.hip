@@ -672,6 +672,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     const u32 max_blocks = (u32)c->n_cus * blocks_per_cu;
     const Params& q = c->P;
     const bool defp = q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3;
+    // the long-genome parameters (--mal 15 --msl 9 --reg 60, BASELINE configs[3]): the second set the pair kernel folds into
+    // its code, the hand-written null chain included (bitmap and join forms)
+    const bool lgp = q.mal == 15 && q.msl == 9 && q.mrd == 40 && q.mqd == 40 && q.reg == 60 && q.aw == 15 && q.am == 7 && q.ar == 3;
     std::vector<char> launched(n_batches, 0);
     const char* const bkenv = getenv("LZANI_BLOCK_KERNEL");
     DevBuf<unsigned long long> d_cbits;                      // join form: one candidate bitmap per resident wave
@@ -790,15 +793,19 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             } else if (!fast) LZ_PAIRS(false, false, false, false, false);
             else if (pm) {                              // dense rows: candidate bitmaps made ahead (k_pm_cand)
                 c->pm_launches += 1;
-                if (nf && defp) LZ_PAIRS_PM(true, true);
-                else if (nf) LZ_PAIRS_PM(true, false);
-                else if (defp) LZ_PAIRS_PM(false, true);
-                else LZ_PAIRS_PM(false, false);
+                if (nf && defp) LZ_PAIRS_PM(true, 1);
+                else if (nf && lgp) LZ_PAIRS_PM(true, 2);
+                else if (nf) LZ_PAIRS_PM(true, 0);
+                else if (defp) LZ_PAIRS_PM(false, 1);
+                else if (lgp) LZ_PAIRS_PM(false, 2);
+                else LZ_PAIRS_PM(false, 0);
             } else if (tw && pa.skeys) {                // long genomes: candidates by the join
-                if (nf && defp) LZ_PAIRS_JOIN(true, true);
-                else if (nf) LZ_PAIRS_JOIN(true, false);
-                else if (defp) LZ_PAIRS_JOIN(false, true);
-                else LZ_PAIRS_JOIN(false, false);
+                if (nf && defp) LZ_PAIRS_JOIN(true, 1);
+                else if (nf && lgp) LZ_PAIRS_JOIN(true, 2);
+                else if (nf) LZ_PAIRS_JOIN(true, 0);
+                else if (defp) LZ_PAIRS_JOIN(false, 1);
+                else if (lgp) LZ_PAIRS_JOIN(false, 2);
+                else LZ_PAIRS_JOIN(false, 0);
             } else if (use_blk) {
                 const u32 fw = (u32)std::max<u64>(c->fl_stride >> c->blk_fold, 1);
                 const size_t lds = (size_t)(BLK_WAVES * SEED_LDS_WORDS + fw) * 4;

@@ -18,7 +18,7 @@ struct GenomeTab {
     const u64* nmoff;    // per genome: word offset into nm (t2 offset is twice that, k-mer arrays 64x)
     const int* L;        // per genome: sequence length
     const u32* kmL;      // per text position: mix_key(mal-mer) or KM_INVALID   (fast path: mal, msl <= 15)
-    const u32* kmS;      // per text position: msl-mer or KM_INVALID
+    const u32* kmS;      // per text position: msl-mer (msl 8, 9: with 14 hash bits above it, k_kmers) or KM_INVALID
     const int* hasN;     // per genome: 1 if the sequence holds a non-ACGT symbol
 };
 
@@ -38,7 +38,17 @@ __global__ void k_kmers(GenomeTab G, u32* __restrict__ kmL, u32* __restrict__ km
     u64 key;
     u32 a = KM_INVALID, b = KM_INVALID;
     if (kmer_at(R, p, mal, key)) a = (u32)mix_key(key, 2 * mal);
-    if (kmer_at(R, p, msl, key)) b = (u32)key;
+    if (kmer_at(R, p, msl, key)) {
+        b = (u32)key;
+        // msl 8, 9: 14 hash bits above the msl-mer -- word and bit of the pair kernel's seed bitmap (DevWave::bm_hash,
+        // LZ_NC_WORD9) without a multiply per round; 0x3FFF stays KM_INVALID's alone.  Equality of two words is still
+        // equality of the msl-mers.
+        if (msl == 8 || msl == 9) {
+            u32 h = (b * 0x9E3779B1u) >> 18;
+            h = h == 0x3FFFu ? 0x3FFEu : h;
+            b |= h << (2 * msl);
+        }
+    }
     kmL[64 * o + p] = a;
     kmS[64 * o + p] = b;
 }

@@ -31,9 +31,9 @@ __device__ __forceinline__ u64 wballot(bool b) { return __builtin_amdgcn_ballot_
 // a byte in all four bytes of a word: one byte permute (a 32-bit multiply by 0x01010101 runs at quarter rate)
 __device__ __forceinline__ u32 rep4(u32 b) { return __builtin_amdgcn_perm(b, b, 0u); }
 
-template <bool FAST, bool BK = false, bool JOIN = false, bool CHAIN = false, bool LFLT = false>
+template <bool FAST, bool BK = false, bool JOIN = false, int CHAIN = 0, bool LFLT = false>
 struct DevWave {
-    static constexpr bool NULL_CHAIN = CHAIN;
+    static constexpr bool NULL_CHAIN = CHAIN != 0;      // (1 = the default parameters, 2 = mal 15, msl 9, reg 60: see pair_body)
     const Params& P;
     TextView R, Q;
     IndexView I;
@@ -206,7 +206,8 @@ struct DevWave {
     //     (ascending = the order of the reference's bucket) - no join structure at all.
     __device__ __forceinline__ u32 bm_hash(u32 k) const
     {
-        return P.msl <= 7 ? k : (k * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
+        // (msl 8, 9: k_kmers packs 14 hash bits above the msl-mer)
+        return P.msl <= 7 ? k : P.msl <= 9 ? k >> (2 * P.msl) : (k * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
     }
     __device__ __forceinline__ bool seed_prefilter(u32 rk0, u32 rk1, u32 qk) const
     {
@@ -472,23 +473,34 @@ struct DevWave {
             // every lane peels its own candidates into the compaction buffer, lowest bit first -- as many turns as the
             // fullest word has candidates (~5 for chance anchors).  Ranks 0 .. AQ_CAP go out (the last one only to tell
             // the next refill where to start).
+            // Two such blocks are requested together; the second one is peeled only if the first leaves room in the queue
+            // (sparse candidates: long k-mers -- a queue then covers twice the positions, and a refill is a chain of
+            // dependent memory round trips the wave sits out).
             const u32 w0 = (u32)scan_pos >> 6;
-            const int p_lo = (int)((w0 + (u32)lane) << 6);                  // first position of this lane's word
+            const int p_lo = (int)((w0 + (u32)lane) << 6), p_hi = p_lo + 4096;  // first position of this lane's words
             unsigned long long x = cand_bits[p_lo < iend ? w0 + (u32)lane : w0];
+            unsigned long long x2 = cand_bits[p_hi < iend ? w0 + 64u + (u32)lane : w0];
             x &= ~lowmask(scan_pos - p_lo) & lowmask(iend - p_lo);          // positions in [scan_pos, iend)
-            const int cnt = popc64(x);
-            const int incl = wave_incl_scan(cnt);
-            int at = incl - cnt;
-            ncand = __builtin_amdgcn_readlane(incl, 63);
-            while (wballot((x != 0) & (at <= AQ_CAP)) != 0) {
-                const bool has = (x != 0) & (at <= AQ_CAP);
-                const u32 lo = (u32)x, hi = (u32)(x >> 32);
-                const int b = lo ? (int)__builtin_ctz(lo) : 32 + (int)__builtin_ctz(hi | 0x80000000u);
-                cq[has ? at : AQ_LDS_CAND - 1] = (u32)(p_lo + b);
-                x &= x - 1;
-                at += 1;
+            x2 = p_hi < iend ? x2 & lowmask(iend - p_hi) : 0ULL;
+            int blocks = 1, base = 0;
+            for (;;) {
+                const int cnt = popc64(x);
+                const int incl = wave_incl_scan(cnt);
+                int at = base + incl - cnt;
+                ncand = base + __builtin_amdgcn_readlane(incl, 63);
+                int p0 = blocks == 1 ? p_lo : p_hi;
+                while (wballot((x != 0) & (at <= AQ_CAP)) != 0) {
+                    const bool has = (x != 0) & (at <= AQ_CAP);
+                    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+                    const int b = lo ? (int)__builtin_ctz(lo) : 32 + (int)__builtin_ctz(hi | 0x80000000u);
+                    cq[has ? at : AQ_LDS_CAND - 1] = (u32)(p0 + b);
+                    x &= x - 1;
+                    at += 1;
+                }
+                if (blocks == 2 || ncand >= AQ_CAP || (int)((w0 + 64u) << 6) >= iend) break;      // wave-uniform
+                blocks = 2; base = ncand; x = x2;
             }
-            scan_pos = imin((int)((w0 + 64u) << 6), iend);                  // (more than AQ_CAP candidates: corrected below)
+            scan_pos = imin((int)((w0 + 64u * (u32)blocks) << 6), iend);    // (more than AQ_CAP candidates: corrected below)
         }
         for (int turn = 0; !JOIN && turn < AQ_MAXCHUNKS / 4 && scan_pos < iend && ncand < AQ_CAP; ++turn) {
             u32 hq[4], w[4];
@@ -633,7 +645,7 @@ struct DevWave {
     // dropped.)  Only "no seed candidate in j's tracking round" is left to the loop.  The parameters are the defaults.
     __device__ __forceinline__ void chain_classes()
     {
-        enum { MQD = 40, MRD = 40, MSL = 7, REG = 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };
+        enum { MQD = 40, MRD = 40, MSL = CHAIN == 2 ? 9 : 7, REG = CHAIN == 2 ? 60 : 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };
         const int ilim = imin(scan_pos, iend) - NT, rlim = R.len - MSL + 1 - WIN;
         const int len = a_len;
         const bool plain = len > 0;
@@ -770,7 +782,7 @@ struct DevWave {
                                               int& add_tm, int& add_tl, int& add_tc)
     {
         static_assert(!CHAIN || (FAST && BK), "the null chain reads the anchor queue");
-        enum { MQD = 40, MRD = 40, MSL = 7, REG = 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };    // params.h:34-48
+        enum { MQD = 40, MRD = 40, MSL = CHAIN == 2 ? 9 : 7, REG = CHAIN == 2 ? 60 : 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };    // params.h:34-48 (CHAIN == 2: --msl 9 --reg 60)
         const int ilim = imin(scan_pos, iend) - NT;             // the queue and the query cover the tracking steps of i <= ilim
         const int rlim = R.len - MSL + 1 - WIN;                 // the seed window of r_end <= rlim is complete
         const u32 ldsb = (u32)(size_t)bitmap;                   // LDS byte offset (low half of the flat address)
@@ -807,16 +819,6 @@ struct DevWave {
         // the three loads of a tracking round (msl-mers of the 41 steps and of the 80 window positions).  The lanes beyond
         // (steps >= NT, window positions >= WIN) are not masked: their steps are cut from the result (LZ_NC_SEEDS), their
         // window positions are positions of the first load again; what leaves the loop with the round in hand is masked then (LZ_NC_FIX)
-#ifdef LZANI_EXP_CACHED                             // diagnostic build (wrong results): the window k-mers from one cached place
-#define LZ_NC_LOADS_X(I, R, QK, K0, K1) \
-            "s_and_b32 %[t0], %[" R "], 0x3ff\n\t" \
-            "v_add_lshl_u32 %[a0], %[lane], %[" I "], 2\n\t" \
-            "v_add_lshl_u32 %[a1], %[lane], %[t0], 2\n\t" \
-            "v_add_lshl_u32 %[aq], %[w1], %[t0], 2\n\t" \
-            "global_load_dword %[" QK "], %[a0], %[qks]\n\t" \
-            "global_load_dword %[" K0 "], %[a1], %[rks]\n\t" \
-            "global_load_dword %[" K1 "], %[aq], %[rks]\n\t"
-#else
 #define LZ_NC_LOADS_X(I, R, QK, K0, K1) \
             "v_add_lshl_u32 %[a0], %[lane], %[" I "], 2\n\t" \
             "v_add_lshl_u32 %[a1], %[lane], %[" R "], 2\n\t" \
@@ -824,60 +826,56 @@ struct DevWave {
             "global_load_dword %[" QK "], %[a0], %[qks]\n\t" \
             "global_load_dword %[" K0 "], %[a1], %[rks]\n\t" \
             "global_load_dword %[" K1 "], %[aq], %[rks]\n\t"
-#endif
 #define LZ_NC_LOADS_F LZ_NC_LOADS_X("i", "rend", "qk", "rk0", "rk1")
         // the round itself (track_round + seed_prefilter): window k-mers into the LDS bitmap, every step tests its own, the
         // bits are cleared again; leaves the steps with a seed candidate in seed.  A lane without a k-mer (KM_INVALID >> 5 is
         // beyond every word of the bitmap) works on its own word behind the bitmap (SEED_PAD) by a minimum: no lane select,
         // no mask (a step without a k-mer may see its own window position's bit there: LZ_NC_FIX)
-#ifdef LZANI_EXP_LDSLIN                             // diagnostic build (wrong results): every lane on its own LDS bank
-#define LZ_NC_ROUND_X(WAIT, QK, K0, K1) \
+        // (word and bit of a k-mer word in the bitmap: msl 7 = the msl-mer itself, 14 bits; msl 9 = the 14 hash bits k_kmers packs
+        // above the msl-mer, where KM_INVALID falls on a bit no msl-mer's hash takes)
+#define LZ_NC_WORD7(A, T, K) \
+            "v_lshrrev_b32_e32 %[" A "], 5, %[" K "]\n\t" \
+            "v_lshlrev_b32_e32 %[" T "], %[" K "], %[one]\n\t" \
+            "v_min_u32_e32 %[" A "], %[dumv], %[" A "]\n\t" \
+            "v_lshl_add_u32 %[" A "], %[" A "], 2, %[ldsb]\n\t"
+#define LZ_NC_WORD9(A, T, K) \
+            "v_lshrrev_b32_e32 %[" A "], 23, %[" K "]\n\t" \
+            "v_lshrrev_b32_e32 %[" T "], 18, %[" K "]\n\t" \
+            "v_lshlrev_b32_e32 %[" T "], %[" T "], %[one]\n\t" \
+            "v_lshl_add_u32 %[" A "], %[" A "], 2, %[ldsb]\n\t"
+#define LZ_NC_ROUND_X(WORD, WAIT, QK, K0, K1) \
             WAIT "\n\t" \
-            "v_and_b32_e32 %[a0], 31, %[lane]\n\t" \
-            "v_lshlrev_b32_e32 %[t], %[" K0 "], %[one]\n\t" \
-            "v_min_u32_e32 %[a0], %[dumv], %[a0]\n\t" \
-            "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t" \
+            WORD("a0", "t", K0) \
             "ds_or_b32 %[a0], %[t]\n\t" \
-            "v_and_b32_e32 %[a1], 31, %[lane]\n\t" \
-            "v_lshlrev_b32_e32 %[bq], %[" K1 "], %[one]\n\t" \
-            "v_min_u32_e32 %[a1], %[dumv], %[a1]\n\t" \
-            "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t" \
+            WORD("a1", "bq", K1) \
             "ds_or_b32 %[a1], %[bq]\n\t" \
-            "v_lshrrev_b32_e32 %[aq], 5, %[" QK "]\n\t" \
-            "v_lshlrev_b32_e32 %[t], %[" QK "], %[one]\n\t" \
-            "v_min_u32_e32 %[aq], %[dumv], %[aq]\n\t" \
-            "v_lshl_add_u32 %[aq], %[lane], 2, %[ldsb]\n\t" \
+            WORD("aq", "t", QK) \
             "ds_read_b32 %[aq], %[aq]\n\t" \
             "ds_write_b32 %[a0], %[zero]\n\t" \
             "ds_write_b32 %[a1], %[zero]\n\t" \
             "s_waitcnt lgkmcnt(2)\n\t" \
             "v_and_b32_e32 %[aq], %[aq], %[t]\n\t" \
             "v_cmp_ne_u32_e64 %[seed], 0, %[aq]\n\t"
-#else
-#define LZ_NC_ROUND_X(WAIT, QK, K0, K1) \
-            WAIT "\n\t" \
-            "v_lshrrev_b32_e32 %[a0], 5, %[" K0 "]\n\t" \
-            "v_lshlrev_b32_e32 %[t], %[" K0 "], %[one]\n\t" \
-            "v_min_u32_e32 %[a0], %[dumv], %[a0]\n\t" \
-            "v_lshl_add_u32 %[a0], %[a0], 2, %[ldsb]\n\t" \
-            "ds_or_b32 %[a0], %[t]\n\t" \
-            "v_lshrrev_b32_e32 %[a1], 5, %[" K1 "]\n\t" \
-            "v_lshlrev_b32_e32 %[bq], %[" K1 "], %[one]\n\t" \
-            "v_min_u32_e32 %[a1], %[dumv], %[a1]\n\t" \
-            "v_lshl_add_u32 %[a1], %[a1], 2, %[ldsb]\n\t" \
-            "ds_or_b32 %[a1], %[bq]\n\t" \
-            "v_lshrrev_b32_e32 %[aq], 5, %[" QK "]\n\t" \
-            "v_lshlrev_b32_e32 %[t], %[" QK "], %[one]\n\t" \
-            "v_min_u32_e32 %[aq], %[dumv], %[aq]\n\t" \
-            "v_lshl_add_u32 %[aq], %[aq], 2, %[ldsb]\n\t" \
-            "ds_read_b32 %[aq], %[aq]\n\t" \
-            "ds_write_b32 %[a0], %[zero]\n\t" \
-            "ds_write_b32 %[a1], %[zero]\n\t" \
-            "s_waitcnt lgkmcnt(2)\n\t" \
-            "v_and_b32_e32 %[aq], %[aq], %[t]\n\t" \
-            "v_cmp_ne_u32_e64 %[seed], 0, %[aq]\n\t"
-#endif
-#define LZ_NC_ROUND_F LZ_NC_ROUND_X("s_waitcnt vmcnt(0)", "qk", "rk0", "rk1")
+#define LZ_NC_ROUND_F(WORD) LZ_NC_ROUND_X(WORD, "s_waitcnt vmcnt(0)", "qk", "rk0", "rk1")
+        // one fast turn (see Lnc_fast)
+#define LZ_NC_FTURN(WORD, P, N, IC, IN, RN, CQ, C0, C1, NQ, N0, N1, SFX) \
+            "Lnc_fturn" SFX "_%=:\n\t" \
+            "s_bitcmp0_b32 %[" P "], 15\n\t" \
+            "s_cbranch_scc1 Lnc_fnogo" SFX "_%=\n\t" \
+            "s_bfe_u32 %[qh], %[" P "], 0x70008\n\t"        /* the successor (the entries between are passed) */ \
+            "v_readlane_b32 %[" N "], %[alen], %[qh]\n\t"   /* (its word: bits 17..24 = the match and its forward extension) */ \
+            "v_readlane_b32 %[ap], %[apos], %[qh]\n\t" \
+            "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t" \
+            "s_bfe_u32 %[t0], %[" N "], 0x80011\n\t" \
+            "s_sub_i32 %[gap], %[ap], %[" IC "]\n\t" \
+            "s_add_i32 %[" IN "], %[ap], %[t0]\n\t" \
+            "s_add_i32 %[" RN "], %[bpos], %[t0]\n\t" \
+            LZ_NC_LOADS_X(IN, RN, NQ, N0, N1) \
+            LZ_NC_ROUND_X(WORD, "s_waitcnt vmcnt(3)", CQ, C0, C1) \
+            LZ_NC_SEEDS \
+            "s_cbranch_scc1 Lnc_frec" SFX "_%=\n\t"         /* a seed candidate: the state first, then the seed event */ \
+            "s_mov_b32 %[t2], %[qh]\n\t" \
+            LZ_NC_COUNT
         // the lane masks a round went without, for what leaves the loop with the round in hand (find_event, the seed event)
 #define LZ_NC_FIX \
             "s_bfm_b64 %[m2], %[NT], 0\n\t" \
@@ -922,549 +920,536 @@ struct DevWave {
         const int qend = __builtin_amdgcn_readfirstlane((R.nfree && Q.nfree) ? iend : -(1 << 30));
         // (the machine's accumulators may live in vector registers -- they come out of popcounts: as scalars for the loop)
         const int ocl_u = __builtin_amdgcn_readfirstlane(open_cl), oclit_u = __builtin_amdgcn_readfirstlane(open_clit);
-        asm volatile(
-            "s_mov_b32 %[code], 0\n\t"
-            "s_mov_b32 %[lastb], 0\n\t"
-            "s_mov_b32 %[lastlit], 0\n\t"
-            "s_mov_b32 %[atm], 0\n\t"
-            "s_mov_b32 %[atl], 0\n\t"
-            "s_mov_b32 %[atc], 0\n\t"
-            "s_mov_b64 %[m2], -1\n\t"                      // (0 = the seed candidates of the turn that follows are known to be false, Lnc_snone)
-            // the window positions of a round's third load: 64 + lane up to the window's last, then the positions from 0 on
-            // again (their bits are set already, and no two lanes of one LDS atomic meet on a word more often than k-mers do)
-            "v_add_u32_e32 %[w1], 64, %[lane]\n\t"
-            "v_subrev_u32_e32 %[dumv], %[WIN], %[w1]\n\t"
-            "v_min_u32_e32 %[w1], %[w1], %[dumv]\n\t"
-            "v_add_u32_e32 %[dumv], %[wdum], %[lane]\n\t"  // a lane's own word behind the bitmap
-            "s_nop 3\n"
-            "Lnc_top_%=:\n\t"
-            // the queue head: candidates the last match has passed go
-            "s_cmp_ge_i32 %[qh], %[qc]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "v_readlane_b32 %[t0], %[apos], %[qh]\n\t"
-            "s_cmp_ge_i32 %[t0], %[i]\n\t"
-            "s_cbranch_scc1 Lnc_nodrop_%=\n\t"
-            "v_cmp_le_i32_e32 vcc, %[qh], %[lane]\n\t"
-            "v_cmp_le_i32_e64 %[m], %[i], %[apos]\n\t"
-            "s_and_b64 %[m], %[m], vcc\n\t"
-            "s_ff1_i32_b64 %[qh], %[m]\n\t"
-            "s_min_u32 %[qh], %[qh], 64\n\t"
-            "s_cmp_ge_i32 %[qh], %[qc]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n"
-            "Lnc_nodrop_%=:\n\t"
-            "s_cmp_gt_i32 %[i], %[ilim]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_cmp_gt_i32 %[rend], %[rlim]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            LZ_NC_LOADS_F
-            // While the loads fly: the next queued candidate and, should the round find no seed candidate, whether it is
-            // a null event (t2 = 1): plain, distant, the open region short (dropped), both extensions empty by the record
-            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t"
-            "v_readlane_b32 %[ap], %[apos], %[qh]\n\t"
-            "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t"
-            "v_readlane_b32 %[rec], %[aext], %[qh]\n\t"
-            "s_mov_b32 %[t2], 0\n\t"
-            "s_mov_b32 %[cls], 0\n\t"                        // (1 = the open region is kept, or there is none; bit 15 = a fast turn, Lnc_snone)
-            "s_bfe_u32 %[code], %[blen], 0x10010\n\t"       // chain_classes' bit 16: plain, both extensions in the record, aw symbols into both texts
-            "s_sext_i32_i8 %[blen], %[blen]\n\t"            // (the rest of the word is chain_classes')
-            "s_sub_i32 %[gap], %[ap], %[i]\n\t"
-            "s_cmp_lt_i32 %[blen], 1\n\t"
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
-            "s_cmp_le_i32 %[gap], %[MQD]\n\t"
-            "s_cbranch_scc1 Lnc_close_%=\n"
-            "Lnc_distant_%=:\n\t"
-            "s_cmp_lt_i32 %[prs], 0\n\t"
-            "s_cbranch_scc1 Lnc_kept_%=\n\t"
-            "s_sub_i32 %[t1], %[pre], %[prs]\n\t"
-            "s_cmp_ge_i32 %[t1], %[REG]\n\t"
-            "s_cbranch_scc1 Lnc_kept_%=\n\t"
-            "s_sub_i32 %[t1], %[ap], %[prs]\n\t"
-            "s_add_i32 %[t1], %[t1], %[plit]\n"             // avail: the dropped region and the literals before it
-            "Lnc_avail_%=:\n\t"
-            // the short cut: the candidate's own properties are in bit 16; with at least aw symbols to look back at, its
-            // reach is >= aw and the backward extension is the record's
-            "s_cmp_eq_u32 %[code], 0\n\t"
-            "s_cbranch_scc1 Lnc_gen_%=\n\t"
-            "s_cmp_lt_i32 %[t1], %[AW]\n\t"
-            "s_cbranch_scc1 Lnc_gen_%=\n\t"
-            "s_and_b32 %[kb], %[rec], 15\n\t"
-            "s_bfe_u32 %[kc], %[rec], 0x40004\n\t"
-            "s_mov_b32 %[fok], 1\n\t"
-            "s_branch Lnc_ok_%=\n"
-            "Lnc_gen_%=:\n\t"
-            "s_bitcmp0_b32 %[rec], 29\n\t"                  // the forward extension must be in the record (empty or not)
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
-            "s_min_i32 %[t0], %[t1], %[ap]\n\t"
-            "s_min_i32 %[t0], %[t0], %[bpos]\n\t"           // reach
-            "s_mov_b32 %[kb], 0\n\t"                          // the backward extension: empty, unless the record holds it
-            "s_mov_b32 %[kc], 0\n\t"
-            "s_mov_b32 %[fok], 0\n\t"
-            "s_cmp_lt_i32 %[t0], 1\n\t"
-            "s_cbranch_scc1 Lnc_ok_%=\n\t"
-            "s_bitcmp1_b32 %[rec], 30\n\t"
-            "s_cbranch_scc1 Lnc_brkb_%=\n\t"
-            "s_min_i32 %[code], %[t0], %[AW]\n\t"           // no break inside the first aw symbols: the qual bits decide,
-            "s_bfm_b32 %[code], %[code], 0\n\t"             // if the machine may not look further back than they reach
-            "s_and_b32 %[code], %[code], %[rec]\n\t"
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
-            "s_cmp_le_i32 %[t0], %[AW]\n\t"
-            "s_cbranch_scc1 Lnc_ok_%=\n\t"
-            "s_branch Lnc_chk_%=\n"
-            "Lnc_brkb_%=:\n\t"                               // the scan breaks inside them: its result is in the record
-            "s_cmp_lt_i32 %[t0], %[AW]\n\t"                 // (given the full first window)
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
-            "s_and_b32 %[kb], %[rec], 15\n\t"
-            "s_bfe_u32 %[kc], %[rec], 0x40004\n\t"
-            "s_mov_b32 %[fok], 1\n"                          // committed by its record: what chain_classes assumes
-            "Lnc_ok_%=:\n\t"
-            "s_mov_b32 %[t2], 1\n"
-            "Lnc_chk_%=:\n\t"
-            LZ_NC_ROUND_F
-            "s_mov_b32 %[code], 1\n\t"
-            LZ_NC_SEEDS
-            "s_cbranch_scc1 Lnc_sseed_%=\n"                 // a seed candidate: the round is done; the event itself, if it is simple
-            "Lnc_noseed_%=:\n\t"
-            "s_cmp_lt_i32 %[blen], 1\n\t"
-            "s_cbranch_scc1 Lnc_npl_%=\n\t"                 // the candidate is not plain: likewise
-            "s_mov_b32 %[code], 2\n\t"
-            "s_cmp_eq_u32 %[t2], 0\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the event is found but is not a null event
-            "s_cmp_eq_u32 %[cls], 0\n\t"
-            "s_cbranch_scc1 Lnc_commit_%=\n\t"
-            // the open region is kept (not dropped): calc_stats' step at the match_distant factor that follows -- it counts
-            // if its matches and literals reach reg (parser.cpp:743-751, 775).  The open region is the last committed
-            // event's if this call has committed any, else the machine's
-            "s_cmp_lg_u32 %[lastb], 0\n\t"
-            "s_cselect_b32 %[t0], %[lastb], %[ocl]\n\t"
-            "s_cselect_b32 %[t2], %[lastlit], %[oclit]\n\t"
-            "s_cmp_eq_u32 %[t0], 0\n\t"
-            "s_cbranch_scc1 Lnc_commit_%=\n\t"
-            "s_add_i32 %[t2], %[t2], %[t0]\n\t"
-            "s_cmp_lt_i32 %[t2], %[REG]\n\t"
-            "s_cbranch_scc1 Lnc_commit_%=\n\t"
-            "s_sub_i32 %[t2], %[t2], %[t0]\n\t"
-            "s_add_i32 %[atm], %[atm], %[t0]\n\t"
-            "s_add_i32 %[atl], %[atl], %[t2]\n\t"
-            "s_add_i32 %[atc], %[atc], 1\n"
-            "Lnc_commit_%=:\n\t"
-            LZ_NC_COMMIT
-            "s_mov_b32 %[code], 0\n\t"
-            "s_cmp_eq_u32 %[fok], 0\n\t"
-            "s_cbranch_scc1 Lnc_top_%=\n"
-            // The fast turn: the candidate just committed (queue entry qh - 1) was a null event by its record, so
-            // chain_classes' word says which entry the scan meets next and whether that is the next null event for
-            // certain (GO) -- then only this entry's tracking round is left to do
-            "Lnc_fast_%=:\n\t"
-            // (inside a run of fast turns the machine's state is kept as far as the turns need it: i, rend, the queue head;
-            // what the general turn and the seed event need besides -- prs, plit, pre, the open region -- is a function of
-            // the last committed entry and of fok = prs - plit, the same for every null event over a dropped region, and is
-            // rebuilt when the run ends, Lnc_frec)
-            "s_sub_i32 %[fok], %[prs], %[plit]\n\t"
-            "s_sub_i32 %[t2], %[qh], 1\n\t"                // the last committed entry (t2 stays untouched to the end of the turn)
-            "v_readlane_b32 %[cls], %[alen], %[t2]\n"      // its word
-            "Lnc_fstart_%=:\n\t"
-            LZ_NC_LOADS_F
-            // Two turns a pass, in two sets of registers that take turns: a turn requests the k-mers of the NEXT turn's round
-            // -- where that round stands follows from the successor's queue entry alone, not from this round's outcome --
-            // before it waits for its own, so the loads of one turn fly during the LDS phase of the turn before.  A turn that
-            // ends the run (no GO, a seed candidate) leaves the request behind; what leaves the second turn puts the
-            // registers back: cls the committed entry's word, blen the successor's, i / rend the round's, qk / rk0 / rk1 its k-mers.
-#define LZ_NC_FTURN(P, N, IC, IN, RN, CQ, C0, C1, NQ, N0, N1, SFX) \
-            "Lnc_fturn" SFX "_%=:\n\t" \
-            "s_bitcmp0_b32 %[" P "], 15\n\t" \
-            "s_cbranch_scc1 Lnc_fnogo" SFX "_%=\n\t" \
-            "s_bfe_u32 %[qh], %[" P "], 0x70008\n\t"        /* the successor (the entries between are passed) */ \
-            "v_readlane_b32 %[" N "], %[alen], %[qh]\n\t"   /* (its word: bits 17..24 = the match and its forward extension) */ \
+#define LZ_NC_ASM(WORD) \
+        asm volatile( \
+            "s_mov_b32 %[code], 0\n\t" \
+            "s_mov_b32 %[lastb], 0\n\t" \
+            "s_mov_b32 %[lastlit], 0\n\t" \
+            "s_mov_b32 %[atm], 0\n\t" \
+            "s_mov_b32 %[atl], 0\n\t" \
+            "s_mov_b32 %[atc], 0\n\t" \
+            "s_mov_b64 %[m2], -1\n\t"                      /* (0 = the seed candidates of the turn that follows are known to be false, Lnc_snone) */ \
+            /* the window positions of a round's third load: 64 + lane up to the window's last, then the positions from 0 on */ \
+            /* again (their bits are set already, and no two lanes of one LDS atomic meet on a word more often than k-mers do) */ \
+            "v_add_u32_e32 %[w1], 64, %[lane]\n\t" \
+            "v_subrev_u32_e32 %[dumv], %[WIN], %[w1]\n\t" \
+            "v_min_u32_e32 %[w1], %[w1], %[dumv]\n\t" \
+            "v_add_u32_e32 %[dumv], %[wdum], %[lane]\n\t"  /* a lane's own word behind the bitmap */ \
+            "s_nop 3\n" \
+            "Lnc_top_%=:\n\t" \
+            /* the queue head: candidates the last match has passed go */ \
+            "s_cmp_ge_i32 %[qh], %[qc]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            "v_readlane_b32 %[t0], %[apos], %[qh]\n\t" \
+            "s_cmp_ge_i32 %[t0], %[i]\n\t" \
+            "s_cbranch_scc1 Lnc_nodrop_%=\n\t" \
+            "v_cmp_le_i32_e32 vcc, %[qh], %[lane]\n\t" \
+            "v_cmp_le_i32_e64 %[m], %[i], %[apos]\n\t" \
+            "s_and_b64 %[m], %[m], vcc\n\t" \
+            "s_ff1_i32_b64 %[qh], %[m]\n\t" \
+            "s_min_u32 %[qh], %[qh], 64\n\t" \
+            "s_cmp_ge_i32 %[qh], %[qc]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n" \
+            "Lnc_nodrop_%=:\n\t" \
+            "s_cmp_gt_i32 %[i], %[ilim]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            "s_cmp_gt_i32 %[rend], %[rlim]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            LZ_NC_LOADS_F \
+            /* While the loads fly: the next queued candidate and, should the round find no seed candidate, whether it is */ \
+            /* a null event (t2 = 1): plain, distant, the open region short (dropped), both extensions empty by the record */ \
+            "v_readlane_b32 %[blen], %[alen], %[qh]\n\t" \
             "v_readlane_b32 %[ap], %[apos], %[qh]\n\t" \
             "v_readlane_b32 %[bpos], %[aref], %[qh]\n\t" \
-            "s_bfe_u32 %[t0], %[" N "], 0x80011\n\t" \
-            "s_sub_i32 %[gap], %[ap], %[" IC "]\n\t" \
-            "s_add_i32 %[" IN "], %[ap], %[t0]\n\t" \
-            "s_add_i32 %[" RN "], %[bpos], %[t0]\n\t" \
-            LZ_NC_LOADS_X(IN, RN, NQ, N0, N1) \
-            LZ_NC_ROUND_X("s_waitcnt vmcnt(3)", CQ, C0, C1) \
+            "v_readlane_b32 %[rec], %[aext], %[qh]\n\t" \
+            "s_mov_b32 %[t2], 0\n\t" \
+            "s_mov_b32 %[cls], 0\n\t"                        /* (1 = the open region is kept, or there is none; bit 15 = a fast turn, Lnc_snone) */ \
+            "s_bfe_u32 %[code], %[blen], 0x10010\n\t"       /* chain_classes' bit 16: plain, both extensions in the record, aw symbols into both texts */ \
+            "s_sext_i32_i8 %[blen], %[blen]\n\t"            /* (the rest of the word is chain_classes') */ \
+            "s_sub_i32 %[gap], %[ap], %[i]\n\t" \
+            "s_cmp_lt_i32 %[blen], 1\n\t" \
+            "s_cbranch_scc1 Lnc_chk_%=\n\t" \
+            "s_cmp_le_i32 %[gap], %[MQD]\n\t" \
+            "s_cbranch_scc1 Lnc_close_%=\n" \
+            "Lnc_distant_%=:\n\t" \
+            "s_cmp_lt_i32 %[prs], 0\n\t" \
+            "s_cbranch_scc1 Lnc_kept_%=\n\t" \
+            "s_sub_i32 %[t1], %[pre], %[prs]\n\t" \
+            "s_cmp_ge_i32 %[t1], %[REG]\n\t" \
+            "s_cbranch_scc1 Lnc_kept_%=\n\t" \
+            "s_sub_i32 %[t1], %[ap], %[prs]\n\t" \
+            "s_add_i32 %[t1], %[t1], %[plit]\n"             /* avail: the dropped region and the literals before it */ \
+            "Lnc_avail_%=:\n\t" \
+            /* the short cut: the candidate's own properties are in bit 16; with at least aw symbols to look back at, its */ \
+            /* reach is >= aw and the backward extension is the record's */ \
+            "s_cmp_eq_u32 %[code], 0\n\t" \
+            "s_cbranch_scc1 Lnc_gen_%=\n\t" \
+            "s_cmp_lt_i32 %[t1], %[AW]\n\t" \
+            "s_cbranch_scc1 Lnc_gen_%=\n\t" \
+            "s_and_b32 %[kb], %[rec], 15\n\t" \
+            "s_bfe_u32 %[kc], %[rec], 0x40004\n\t" \
+            "s_mov_b32 %[fok], 1\n\t" \
+            "s_branch Lnc_ok_%=\n" \
+            "Lnc_gen_%=:\n\t" \
+            "s_bitcmp0_b32 %[rec], 29\n\t"                  /* the forward extension must be in the record (empty or not) */ \
+            "s_cbranch_scc1 Lnc_chk_%=\n\t" \
+            "s_min_i32 %[t0], %[t1], %[ap]\n\t" \
+            "s_min_i32 %[t0], %[t0], %[bpos]\n\t"           /* reach */ \
+            "s_mov_b32 %[kb], 0\n\t"                          /* the backward extension: empty, unless the record holds it */ \
+            "s_mov_b32 %[kc], 0\n\t" \
+            "s_mov_b32 %[fok], 0\n\t" \
+            "s_cmp_lt_i32 %[t0], 1\n\t" \
+            "s_cbranch_scc1 Lnc_ok_%=\n\t" \
+            "s_bitcmp1_b32 %[rec], 30\n\t" \
+            "s_cbranch_scc1 Lnc_brkb_%=\n\t" \
+            "s_min_i32 %[code], %[t0], %[AW]\n\t"           /* no break inside the first aw symbols: the qual bits decide, */ \
+            "s_bfm_b32 %[code], %[code], 0\n\t"             /* if the machine may not look further back than they reach */ \
+            "s_and_b32 %[code], %[code], %[rec]\n\t" \
+            "s_cbranch_scc1 Lnc_chk_%=\n\t" \
+            "s_cmp_le_i32 %[t0], %[AW]\n\t" \
+            "s_cbranch_scc1 Lnc_ok_%=\n\t" \
+            "s_branch Lnc_chk_%=\n" \
+            "Lnc_brkb_%=:\n\t"                               /* the scan breaks inside them: its result is in the record */ \
+            "s_cmp_lt_i32 %[t0], %[AW]\n\t"                 /* (given the full first window) */ \
+            "s_cbranch_scc1 Lnc_chk_%=\n\t" \
+            "s_and_b32 %[kb], %[rec], 15\n\t" \
+            "s_bfe_u32 %[kc], %[rec], 0x40004\n\t" \
+            "s_mov_b32 %[fok], 1\n"                          /* committed by its record: what chain_classes assumes */ \
+            "Lnc_ok_%=:\n\t" \
+            "s_mov_b32 %[t2], 1\n" \
+            "Lnc_chk_%=:\n\t" \
+            LZ_NC_ROUND_F(WORD) \
+            "s_mov_b32 %[code], 1\n\t" \
             LZ_NC_SEEDS \
-            "s_cbranch_scc1 Lnc_frec" SFX "_%=\n\t"         /* a seed candidate: the state first, then the seed event */ \
+            "s_cbranch_scc1 Lnc_sseed_%=\n"                 /* a seed candidate: the round is done; the event itself, if it is simple */ \
+            "Lnc_noseed_%=:\n\t" \
+            "s_cmp_lt_i32 %[blen], 1\n\t" \
+            "s_cbranch_scc1 Lnc_npl_%=\n\t"                 /* the candidate is not plain: likewise */ \
+            "s_mov_b32 %[code], 2\n\t" \
+            "s_cmp_eq_u32 %[t2], 0\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 /* the event is found but is not a null event */ \
+            "s_cmp_eq_u32 %[cls], 0\n\t" \
+            "s_cbranch_scc1 Lnc_commit_%=\n\t" \
+            /* the open region is kept (not dropped): calc_stats' step at the match_distant factor that follows -- it counts */ \
+            /* if its matches and literals reach reg (parser.cpp:743-751, 775).  The open region is the last committed */ \
+            /* event's if this call has committed any, else the machine's */ \
+            "s_cmp_lg_u32 %[lastb], 0\n\t" \
+            "s_cselect_b32 %[t0], %[lastb], %[ocl]\n\t" \
+            "s_cselect_b32 %[t2], %[lastlit], %[oclit]\n\t" \
+            "s_cmp_eq_u32 %[t0], 0\n\t" \
+            "s_cbranch_scc1 Lnc_commit_%=\n\t" \
+            "s_add_i32 %[t2], %[t2], %[t0]\n\t" \
+            "s_cmp_lt_i32 %[t2], %[REG]\n\t" \
+            "s_cbranch_scc1 Lnc_commit_%=\n\t" \
+            "s_sub_i32 %[t2], %[t2], %[t0]\n\t" \
+            "s_add_i32 %[atm], %[atm], %[t0]\n\t" \
+            "s_add_i32 %[atl], %[atl], %[t2]\n\t" \
+            "s_add_i32 %[atc], %[atc], 1\n" \
+            "Lnc_commit_%=:\n\t" \
+            LZ_NC_COMMIT \
+            "s_mov_b32 %[code], 0\n\t" \
+            "s_cmp_eq_u32 %[fok], 0\n\t" \
+            "s_cbranch_scc1 Lnc_top_%=\n" \
+            /* The fast turn: the candidate just committed (queue entry qh - 1) was a null event by its record, so */ \
+            /* chain_classes' word says which entry the scan meets next and whether that is the next null event for */ \
+            /* certain (GO) -- then only this entry's tracking round is left to do */ \
+            "Lnc_fast_%=:\n\t" \
+            /* (inside a run of fast turns the machine's state is kept as far as the turns need it: i, rend, the queue head; */ \
+            /* what the general turn and the seed event need besides -- prs, plit, pre, the open region -- is a function of */ \
+            /* the last committed entry and of fok = prs - plit, the same for every null event over a dropped region, and is */ \
+            /* rebuilt when the run ends, Lnc_frec) */ \
+            "s_sub_i32 %[fok], %[prs], %[plit]\n\t" \
+            "s_sub_i32 %[t2], %[qh], 1\n\t"                /* the last committed entry (t2 stays untouched to the end of the turn) */ \
+            "v_readlane_b32 %[cls], %[alen], %[t2]\n"      /* its word */ \
+            "Lnc_fstart_%=:\n\t" \
+            LZ_NC_LOADS_F \
+            /* Two turns a pass, in two sets of registers that take turns: a turn requests the k-mers of the NEXT turn's round */ \
+            /* -- where that round stands follows from the successor's queue entry alone, not from this round's outcome -- */ \
+            /* before it waits for its own, so the loads of one turn fly during the LDS phase of the turn before.  A turn that */ \
+            /* ends the run (no GO, a seed candidate) leaves the request behind; what leaves the second turn puts the */ \
+            /* registers back: cls the committed entry's word, blen the successor's, i / rend the round's, qk / rk0 / rk1 its k-mers. */ \
+            LZ_NC_FTURN(WORD, "cls", "blen", "i", "t1", "kb", "qk", "rk0", "rk1", "qkb", "rk0b", "rk1b", "") \
+            LZ_NC_FTURN(WORD, "blen", "cls", "t1", "i", "rend", "qkb", "rk0b", "rk1b", "qk", "rk0", "rk1", "2") \
+            "s_branch Lnc_fturn_%=\n" \
+            "Lnc_fnogo2_%=:\n\t" \
+            "s_mov_b32 %[i], %[t1]\n\t" \
+            "s_mov_b32 %[rend], %[kb]\n\t" \
+            "s_mov_b32 %[cls], %[blen]\n\t" \
+            "s_branch Lnc_fnogo_%=\n" \
+            "Lnc_frec2_%=:\n\t" \
+            "s_mov_b32 %[i], %[t1]\n\t" \
+            "s_mov_b32 %[rend], %[kb]\n\t" \
+            "s_mov_b32 %[t0], %[cls]\n\t" \
+            "s_mov_b32 %[cls], %[blen]\n\t" \
+            "s_mov_b32 %[blen], %[t0]\n\t" \
+            "s_waitcnt vmcnt(0)\n\t"                        /* (the request left behind is for qk / rk0 / rk1) */ \
+            "v_mov_b32_e32 %[qk], %[qkb]\n\t" \
+            "v_mov_b32_e32 %[rk0], %[rk0b]\n\t" \
+            "v_mov_b32_e32 %[rk1], %[rk1b]\n\t" \
+            "s_branch Lnc_frec_%=\n" \
+            /* back into the run behind a round whose seed candidates were all false (Lnc_snone): the successor's null event */ \
+            "Lnc_fcont_%=:\n\t" \
+            "s_bfe_u32 %[t0], %[blen], 0x80011\n\t" \
+            "s_add_i32 %[i], %[ap], %[t0]\n\t" \
+            "s_add_i32 %[rend], %[bpos], %[t0]\n\t" \
             "s_mov_b32 %[t2], %[qh]\n\t" \
-            LZ_NC_COUNT
-            LZ_NC_FTURN("cls", "blen", "i", "t1", "kb", "qk", "rk0", "rk1", "qkb", "rk0b", "rk1b", "")
-            LZ_NC_FTURN("blen", "cls", "t1", "i", "rend", "qkb", "rk0b", "rk1b", "qk", "rk0", "rk1", "2")
-            "s_branch Lnc_fturn_%=\n"
-            "Lnc_fnogo2_%=:\n\t"
-            "s_mov_b32 %[i], %[t1]\n\t"
-            "s_mov_b32 %[rend], %[kb]\n\t"
-            "s_mov_b32 %[cls], %[blen]\n\t"
-            "s_branch Lnc_fnogo_%=\n"
-            "Lnc_frec2_%=:\n\t"
-            "s_mov_b32 %[i], %[t1]\n\t"
-            "s_mov_b32 %[rend], %[kb]\n\t"
-            "s_mov_b32 %[t0], %[cls]\n\t"
-            "s_mov_b32 %[cls], %[blen]\n\t"
-            "s_mov_b32 %[blen], %[t0]\n\t"
-            "s_waitcnt vmcnt(0)\n\t"                        // (the request left behind is for qk / rk0 / rk1)
-            "v_mov_b32_e32 %[qk], %[qkb]\n\t"
-            "v_mov_b32_e32 %[rk0], %[rk0b]\n\t"
-            "v_mov_b32_e32 %[rk1], %[rk1b]\n\t"
-            "s_branch Lnc_frec_%=\n"
-            // back into the run behind a round whose seed candidates were all false (Lnc_snone): the successor's null event
-            "Lnc_fcont_%=:\n\t"
-            "s_bfe_u32 %[t0], %[blen], 0x80011\n\t"
-            "s_add_i32 %[i], %[ap], %[t0]\n\t"
-            "s_add_i32 %[rend], %[bpos], %[t0]\n\t"
-            "s_mov_b32 %[t2], %[qh]\n\t"
-            "s_mov_b32 %[cls], %[blen]\n\t"
-            LZ_NC_COUNT
-            "s_branch Lnc_fstart_%=\n"
-            "Lnc_fnogo_%=:\n\t"                            // the run ends behind entry t2
-            "s_add_i32 %[qh], %[t2], 1\n"
-            // the machine's state after the null event of entry t2 (see LZ_NC_COMMIT): avail = apos - fok
-            "Lnc_frec_%=:\n\t"
-            "v_readlane_b32 %[t0], %[apos], %[t2]\n\t"
-            "v_readlane_b32 %[t1], %[alen], %[t2]\n\t"
-            "v_readlane_b32 %[kc], %[aext], %[t2]\n\t"
-            "s_sext_i32_i8 %[t1], %[t1]\n\t"
-            "s_and_b32 %[kb], %[kc], 15\n\t"
-            "s_sub_i32 %[prs], %[t0], %[kb]\n\t"
-            "s_sub_i32 %[plit], %[t0], %[fok]\n\t"
-            "s_sub_i32 %[plit], %[plit], %[kb]\n\t"
-            "s_bfe_u32 %[lastlit], %[kc], 0x40014\n\t"
-            "s_bfe_u32 %[t0], %[kc], 0x50018\n\t"
-            "s_add_i32 %[t1], %[t1], %[t0]\n\t"
-            "s_sub_i32 %[lastb], %[t1], %[lastlit]\n\t"
-            "s_bfe_u32 %[t0], %[kc], 0x40004\n\t"
-            "s_add_i32 %[lastb], %[lastb], %[t0]\n\t"
-            "s_add_i32 %[lastlit], %[lastlit], %[kb]\n\t"
-            "s_sub_i32 %[lastlit], %[lastlit], %[t0]\n\t"
-            "s_mov_b32 %[pre], %[i]\n\t"
-            "s_bitcmp0_b32 %[cls], 15\n\t"
-            "s_cbranch_scc1 Lnc_top_%=\n"                   // the run ended at an entry that is not GO: the general turn
-            "Lnc_fseed_%=:\n\t"                             // a seed candidate: as above (the queue head is the successor)
-            "s_mov_b32 %[code], 1\n\t"
-            LZ_NC_FIX
-            "s_cmp_eq_u64 %[m], 0\n\t"                      // (only steps without a k-mer)
-            "s_cbranch_scc1 Lnc_snone_%=\n"
-            // The seed event (code = 1 here; every way out before the last line leaves it so, and seed / rk0 / rk1 / qk
-            // untouched: find_event then does the same from the round).  The simple case is found here: the first step with
-            // a seed candidate lies before the queued candidate's, ONE window position carries its msl-mer, the 64 symbols
-            // behind the msl-mer are real symbols of one strand on both sides (no lane needs a bound) and hold a mismatch:
-            // that is the event -- a seed is at least msl long and no anchor stands at its step to arbitrate with
-            // (parser.cpp:548-580, 604-606) -- adv = the step, bpos, blen = msl + the matching symbols behind.
-            "Lnc_seedev_%=:\n\t"
-            "s_ff1_i32_b64 %[t0], %[m]\n"                   // l
-            "Lnc_sdl_%=:\n\t"
-            LZ_NC_WHY(1)
-            "s_cmp_eq_u32 %[t0], %[gap]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // the queued candidate's own step: arbitration
-            "v_readlane_b32 %[t1], %[qk], %[t0]\n\t"        // the step's msl-mer
-            "s_add_i32 %[t2], %[t0], %[MRD]\n\t"            // its window: the positions idx < l + mrd
-            "s_sub_i32 %[kc], %[t2], 64\n\t"
-            "s_max_i32 %[kc], %[kc], 0\n\t"
-            "s_min_u32 %[kb], %[t2], 64\n\t"
-            "s_sub_i32 %[kb], 64, %[kb]\n\t"                // (the positions of the first load beyond it leave by a shift)
-            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk1]\n\t"
-            "s_bfm_b64 %[m2], %[kc], 0\n\t"
-            "s_and_b64 %[m2], %[m2], vcc\n\t"
-            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk0]\n\t"
-            "s_bcnt1_i32_b64 %[kc], %[m2]\n\t"
-            "s_lshl_b64 vcc, vcc, %[kb]\n\t"
-            "s_bcnt1_i32_b64 %[t1], vcc\n\t"
-            "s_add_i32 %[t2], %[t1], %[kc]\n\t"
-            LZ_NC_WHY(2)
-            "s_cmp_eq_u32 %[t2], 0\n\t"
-            "s_cbranch_scc1 Lnc_sfalse_%=\n\t"              // no window position: the prefilter's false candidate (the bitmap holds all 80 positions)
-            "s_cmp_lg_u32 %[t2], 1\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // several window positions: the longest, then the nearest (find_event)
-            "s_ff1_i32_b64 %[t2], vcc\n\t"
-            "s_sub_i32 %[t2], %[t2], %[kb]\n\t"
-            "s_ff1_i32_b64 %[kc], %[m2]\n\t"
-            "s_add_i32 %[kc], %[kc], 64\n\t"
-            "s_cmp_lg_u32 %[t1], 0\n\t"
-            "s_cselect_b32 %[t2], %[t2], %[kc]\n\t"         // idx
-            "s_add_i32 %[rec], %[rend], %[t2]\n\t"          // the seed in the reference ...
-            "s_add_i32 %[cls], %[i], %[t0]\n\t"             // ... and in the query
-            // bounds: query [cls + 7, cls + 71) inside [0, Lq), Lq = qend - 33 (qend = the scan's end D - msl = Lq + mrd - msl; a pair
-            // with an N in it has qend far below zero); reference the same inside [0, L) or [rc0, rc0 + L), L = (rlim - 34) / 2
-            // (rlim = 2 L + 3 mrd - msl + 1 - 80), rc0 = L + 2 mrd
-            "s_sub_i32 %[t1], %[qend], 104\n\t"
-            LZ_NC_WHY(3)
-            "s_cmp_gt_i32 %[cls], %[t1]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_sub_i32 %[t1], %[rlim], 34\n\t"
-            "s_lshr_b32 %[t1], %[t1], 1\n\t"
-            "s_add_i32 %[t2], %[rec], 71\n\t"
-            "s_cmp_le_i32 %[t2], %[t1]\n\t"
-            "s_cbranch_scc1 Lnc_sok_%=\n\t"
-            "s_add_i32 %[kb], %[t1], 80\n\t"                // rc0
-            "s_cmp_lt_i32 %[rec], %[kb]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // runs from the forward strand into the pad
-            "s_add_i32 %[kb], %[kb], %[t1]\n\t"
-            "s_cmp_gt_i32 %[t2], %[kb]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n"
-            "Lnc_sok_%=:\n\t"
-            "s_add_i32 %[t1], %[rec], 7\n\t"
-            "s_add_i32 %[t2], %[cls], 7\n\t"
-            "v_add_u32_e32 %[a0], %[t1], %[lane]\n\t"
-            "v_add_u32_e32 %[a1], %[t2], %[lane]\n\t"
-            "v_lshrrev_b32_e32 %[aq], 4, %[a0]\n\t"
-            "v_lshrrev_b32_e32 %[t], 4, %[a1]\n\t"
-            "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t"
-            "v_lshlrev_b32_e32 %[t], 2, %[t]\n\t"
-            "global_load_dword %[aq], %[aq], %[rt2]\n\t"
-            "global_load_dword %[t], %[t], %[qt2]\n\t"
-            "v_and_b32_e32 %[a0], 15, %[a0]\n\t"
-            "v_and_b32_e32 %[a1], 15, %[a1]\n\t"
-            "v_lshlrev_b32_e32 %[a0], 1, %[a0]\n\t"
-            "v_lshlrev_b32_e32 %[a1], 1, %[a1]\n\t"
-            "s_waitcnt vmcnt(0)\n\t"
-            "v_lshrrev_b32_e32 %[aq], %[a0], %[aq]\n\t"
-            "v_lshrrev_b32_e32 %[t], %[a1], %[t]\n\t"
-            "v_xor_b32_e32 %[aq], %[aq], %[t]\n\t"
-            "v_and_b32_e32 %[aq], 3, %[aq]\n\t"
-            "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t"
-            "s_nop 0\n\t"
-            LZ_NC_WHY(4)
-            "s_cmp_eq_u64 %[m], 0\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // 64 more symbols match: the general path measures on
-            "s_ff1_i32_b64 %[blen], %[m]\n\t"
-            "s_add_i32 %[blen], %[blen], 7\n\t"
-            "s_mov_b32 %[ap], %[t0]\n\t"
-            "s_mov_b32 %[bpos], %[rec]\n\t"
-            LZ_NC_WHY(5)
-            "s_mov_b32 %[code], 4\n\t"                      // from here on the event is known: any way out hands it to the machine
-            // The close match itself (PairMachine::run: gap_fill, match_run, the first chunk of extend_forward), when every
-            // symbol it looks at is a real symbol of one strand and the forward extension breaks inside its first chunk.
-            // What it does to the open region (cl, clit; nl = 0 before and after): the gap's l symbols give `score` matches
-            // -- the best split's count, compare_ranges_both_ways (parser.cpp:251-374); which split wins a tie only matters to
-            // the alignment output -- and l - score literals, the match blen matches, the extension e - mm and mm.
-            //   t0 = l, rec = the seed in the reference, cls = in the query;  t1 = fq, fok = fr (behind the match)
-            "s_add_i32 %[t1], %[cls], %[blen]\n\t"
-            "s_add_i32 %[t2], %[t1], 64\n\t"
-            "s_sub_i32 %[kb], %[qend], 33\n\t"              // Lq
-            "s_cmp_gt_i32 %[t2], %[kb]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_add_i32 %[fok], %[rec], %[blen]\n\t"
-            "s_add_i32 %[t2], %[fok], 64\n\t"               // the reference side: [rend, fr + 64) on one strand
-            "s_sub_i32 %[kb], %[rlim], 34\n\t"
-            "s_lshr_b32 %[kb], %[kb], 1\n\t"                // L
-            "s_cmp_le_i32 %[t2], %[kb]\n\t"
-            "s_cbranch_scc1 Lnc_hull_%=\n\t"
-            "s_add_i32 %[kc], %[kb], 80\n\t"                // rc0
-            "s_cmp_lt_i32 %[rend], %[kc]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_add_i32 %[kc], %[kc], %[kb]\n\t"
-            "s_cmp_gt_i32 %[t2], %[kc]\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n"
-            "Lnc_hull_%=:\n\t"
-            // to_scan = min(fr - rend, l), shift = l - to_scan; left diagonal (rend, i), right (fr - to_scan, i + shift)
-            "s_sub_i32 %[kb], %[fok], %[rend]\n\t"
-            "s_min_i32 %[kb], %[kb], %[t0]\n\t"             // to_scan (0 when the seed sits at the first step)
-            "s_sub_i32 %[kc], %[t0], %[kb]\n\t"
-            "s_sub_i32 %[gap], %[fok], %[kb]\n\t"           // right diagonal: reference start
-            "s_add_i32 %[kc], %[kc], %[i]\n\t"              //                 query start
-            // six words in flight: the word's byte address ((pos >> 4) << 2) worked out in the register the word lands in
-            "v_add_u32_e32 %[rk0], %[rend], %[lane]\n\t"
-            "v_add_u32_e32 %[rk1], %[i], %[lane]\n\t"
-            "v_add_u32_e32 %[qk], %[gap], %[lane]\n\t"
-            "v_add_u32_e32 %[a0], %[kc], %[lane]\n\t"
-            "v_add_u32_e32 %[a1], %[fok], %[lane]\n\t"
-            "v_add_u32_e32 %[aq], %[t1], %[lane]\n\t"
-            "v_lshrrev_b32_e32 %[rk0], 4, %[rk0]\n\t"
-            "v_lshrrev_b32_e32 %[rk1], 4, %[rk1]\n\t"
-            "v_lshrrev_b32_e32 %[qk], 4, %[qk]\n\t"
-            "v_lshrrev_b32_e32 %[a0], 4, %[a0]\n\t"
-            "v_lshrrev_b32_e32 %[a1], 4, %[a1]\n\t"
-            "v_lshrrev_b32_e32 %[aq], 4, %[aq]\n\t"
-            "v_lshlrev_b32_e32 %[rk0], 2, %[rk0]\n\t"
-            "v_lshlrev_b32_e32 %[rk1], 2, %[rk1]\n\t"
-            "v_lshlrev_b32_e32 %[qk], 2, %[qk]\n\t"
-            "v_lshlrev_b32_e32 %[a0], 2, %[a0]\n\t"
-            "v_lshlrev_b32_e32 %[a1], 2, %[a1]\n\t"
-            "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t"
-            "s_nop 0\n\t"
-            "global_load_dword %[rk0], %[rk0], %[rt2]\n\t"
-            "global_load_dword %[rk1], %[rk1], %[qt2]\n\t"
-            "global_load_dword %[qk], %[qk], %[rt2]\n\t"
-            "global_load_dword %[a0], %[a0], %[qt2]\n\t"
-            "global_load_dword %[a1], %[a1], %[rt2]\n\t"
-            "global_load_dword %[aq], %[aq], %[qt2]\n\t"
-            "s_bfm_b64 %[seed], %[kb], 0\n\t"               // the to_scan lanes of the gap's diagonals (to_scan <= 40)
-            "s_waitcnt vmcnt(0)\n\t"
-            // left diagonal -> m = its matches
-            "v_add_u32_e32 %[t], %[rend], %[lane]\n\t"
-            "v_add_u32_e32 %[bq], %[i], %[lane]\n\t"
-            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t"
-            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t"
-            "v_and_b32_e32 %[t], 30, %[t]\n\t"
-            "v_and_b32_e32 %[bq], 30, %[bq]\n\t"
-            "v_lshrrev_b32_e32 %[rk0], %[t], %[rk0]\n\t"
-            "v_lshrrev_b32_e32 %[rk1], %[bq], %[rk1]\n\t"
-            "v_xor_b32_e32 %[rk0], %[rk0], %[rk1]\n\t"
-            "v_and_b32_e32 %[rk0], 3, %[rk0]\n\t"
-            "v_cmp_eq_u32_e64 %[m], 0, %[rk0]\n\t"
-            // right diagonal -> m2
-            "v_add_u32_e32 %[t], %[gap], %[lane]\n\t"
-            "v_add_u32_e32 %[bq], %[kc], %[lane]\n\t"
-            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t"
-            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t"
-            "v_and_b32_e32 %[t], 30, %[t]\n\t"
-            "v_and_b32_e32 %[bq], 30, %[bq]\n\t"
-            "v_lshrrev_b32_e32 %[qk], %[t], %[qk]\n\t"
-            "v_lshrrev_b32_e32 %[a0], %[bq], %[a0]\n\t"
-            "v_xor_b32_e32 %[qk], %[qk], %[a0]\n\t"
-            "v_and_b32_e32 %[qk], 3, %[qk]\n\t"
-            "v_cmp_eq_u32_e64 %[m2], 0, %[qk]\n\t"
-            // forward chunk -> vcc = its MISmatches
-            "v_add_u32_e32 %[t], %[fok], %[lane]\n\t"
-            "v_add_u32_e32 %[bq], %[t1], %[lane]\n\t"
-            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t"
-            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t"
-            "v_and_b32_e32 %[t], 30, %[t]\n\t"
-            "v_and_b32_e32 %[bq], 30, %[bq]\n\t"
-            "v_lshrrev_b32_e32 %[a1], %[t], %[a1]\n\t"
-            "v_lshrrev_b32_e32 %[aq], %[bq], %[aq]\n\t"
-            "v_xor_b32_e32 %[a1], %[a1], %[aq]\n\t"
-            "v_and_b32_e32 %[a1], 3, %[a1]\n\t"
-            "v_cmp_ne_u32_e32 vcc, 0, %[a1]\n\t"
-            "s_and_b64 %[m], %[m], %[seed]\n\t"             // Lm
-            "s_and_b64 %[m2], %[m2], %[seed]\n\t"           // Rm
-            "s_mov_b64 %[seed], vcc\n\t"                    // Bf
-            // best split: lane s scores popc(Lm below s) + popc(Rm from s on) for s <= to_scan; the maximum is what counts
-            "s_bcnt1_i32_b64 %[t2], %[m2]\n\t"
-            "s_mov_b64 vcc, %[m]\n\t"
-            "s_nop 0\n\t"
-            "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t"
-            "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"
-            "s_mov_b64 vcc, %[m2]\n\t"
-            "s_nop 0\n\t"
-            "v_mbcnt_lo_u32_b32 %[bq], vcc_lo, 0\n\t"
-            "v_mbcnt_hi_u32_b32 %[bq], vcc_hi, %[bq]\n\t"
-            "v_add_u32_e32 %[t], %[t2], %[t]\n\t"
-            "v_sub_u32_e32 %[t], %[t], %[bq]\n\t"
-            "v_cmp_ge_u32_e32 vcc, %[kb], %[lane]\n\t"
-            "s_nop 1\n\t"
-            "v_cndmask_b32_e32 %[t], 0, %[t], vcc\n\t"      // (a split beyond to_scan scores nothing)
-            "s_nop 1\n\t"
-            "v_max_u32_dpp %[t], %[t], %[t] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-            "s_nop 1\n\t"
-            "v_max_u32_dpp %[t], %[t], %[t] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-            "s_nop 1\n\t"
-            "v_max_u32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-            "s_nop 1\n\t"
-            "v_max_u32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-            "s_nop 1\n\t"
-            "v_max_u32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_max_u32_dpp %[t], %[t], %[t] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-            "s_nop 1\n\t"
-            "v_readlane_b32 %[t2], %[t], 63\n\t"            // score
-            // the forward extension's first chunk (try_extend_forward, parser.cpp:377-409; ext_lane): symbol j breaks the scan
-            // if the 15 symbols ending at it hold more than 7 mismatches, and qualifies if it and the two before it match.
-            // The window of lane j = bits [j, j + 15) of Bf << 14, as three words e0 (gap), e1 (kc), e2 (kb)
-            "s_mov_b64 vcc, %[seed]\n\t"
-            "s_lshl_b32 %[gap], vcc_lo, 14\n\t"
-            "s_lshr_b32 %[kb], vcc_lo, 18\n\t"
-            "s_lshl_b32 %[kc], vcc_hi, 14\n\t"
-            "s_or_b32 %[kc], %[kc], %[kb]\n\t"
-            "s_lshr_b32 %[kb], vcc_hi, 18\n\t"
-            "v_mov_b32_e32 %[rk0], %[gap]\n\t"
-            "v_mov_b32_e32 %[rk1], %[kc]\n\t"
-            "v_mov_b32_e32 %[qk], %[kb]\n\t"
-            "v_cmp_gt_u32_e32 vcc, 32, %[lane]\n\t"
-            "v_alignbit_b32 %[a0], %[rk1], %[rk0], %[lane]\n\t"
-            "v_alignbit_b32 %[a1], %[qk], %[rk1], %[lane]\n\t"
-            "v_cndmask_b32_e32 %[a0], %[a1], %[a0], vcc\n\t"
-            "v_and_b32_e32 %[a0], 0x7fff, %[a0]\n\t"
-            "v_bcnt_u32_b32 %[a1], %[a0], 0\n\t"
-            "v_and_b32_e32 %[a0], 0x7000, %[a0]\n\t"
-            "v_cmp_lt_u32_e32 vcc, 7, %[a1]\n\t"            // brk
-            "v_cmp_eq_u32_e64 %[m], 0, %[a0]\n\t"           // qual
-            "s_nop 0\n\t"
-            "s_cmp_eq_u64 vcc, 0\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 // no break inside the chunk: the extension runs on (the general path)
-            "s_ff1_i32_b64 %[kb], vcc\n\t"
-            "s_cmp_ge_u32 %[kb], 63\n\t"
-            "s_cbranch_scc1 Lnc_end_%=\n\t"
-            "s_add_i32 %[kb], %[kb], 1\n\t"
-            "s_bfm_b64 %[m2], %[kb], 0\n\t"
-            "s_and_b64 %[m], %[m], %[m2]\n\t"               // qualifying symbols up to the break
-            "s_mov_b32 %[kb], 0\n\t"                         // e
-            "s_mov_b32 %[kc], 0\n\t"                         // mm
-            "s_cbranch_scc0 Lnc_sext_%=\n\t"
-            "s_flbit_i32_b64 %[kb], %[m]\n\t"
-            "s_sub_i32 %[kb], 64, %[kb]\n\t"                // e = the last qualifying symbol + 1
-            "s_bfm_b64 %[m2], %[kb], 0\n\t"
-            "s_and_b64 %[m2], %[m2], %[seed]\n\t"
-            "s_bcnt1_i32_b64 %[kc], %[m2]\n"                 // mm: the mismatches among its e symbols
-            "Lnc_sext_%=:\n\t"
-            // commit: the open region (the last committed event's, else the machine's) grows by the gap, the match, the extension
-            "s_cmp_lg_u32 %[lastb], 0\n\t"
-            "s_cselect_b32 %[gap], %[lastb], %[ocl]\n\t"
-            "s_cselect_b32 %[rec], %[lastlit], %[oclit]\n\t"
-            "s_add_i32 %[gap], %[gap], %[t2]\n\t"           // + score
-            "s_add_i32 %[gap], %[gap], %[blen]\n\t"
-            "s_add_i32 %[gap], %[gap], %[kb]\n\t"
-            "s_sub_i32 %[lastb], %[gap], %[kc]\n\t"         // cl += score + blen + e - mm
-            "s_add_i32 %[rec], %[rec], %[t0]\n\t"
-            "s_sub_i32 %[rec], %[rec], %[t2]\n\t"
-            "s_add_i32 %[lastlit], %[rec], %[kc]\n\t"       // clit += l - score + mm
-            "s_add_i32 %[i], %[t1], %[kb]\n\t"
-            "s_add_i32 %[rend], %[fok], %[kb]\n\t"
-            "s_mov_b32 %[pre], %[i]\n\t"
-            "s_mov_b32 %[code], 0\n\t"
-            "s_mov_b64 %[m2], -1\n\t"
-            LZ_NC_COUNT
-            "s_branch Lnc_top_%=\n"
-            // a false seed candidate (nine in ten of the rounds that have one): the next one; none left = the round has no seed
-            // candidate after all -- the fast turn goes on where it stood, the general turn is taken again with the flag set
-            "Lnc_sfalse_%=:\n\t"
-            "s_bitset0_b64 %[m], %[t0]\n\t"
-            "s_cmp_eq_u64 %[m], 0\n\t"
-            "s_cbranch_scc1 Lnc_snone_%=\n\t"
-            "s_ff1_i32_b64 %[t0], %[m]\n\t"
-            "s_branch Lnc_sdl_%=\n"
-            "Lnc_snone_%=:\n\t"
-            "s_mov_b32 %[code], 0\n\t"
-            "s_mov_b64 %[m2], -1\n\t"
-            "s_bitcmp1_b32 %[cls], 15\n\t"
-            "s_cbranch_scc1 Lnc_fcont_%=\n\t"
-            "s_mov_b64 %[m2], 0\n\t"
-            "s_branch Lnc_top_%=\n"
-            "Lnc_sseed_%=:\n\t"                            // the general turn's seed candidates: known to be false if this is that second pass
-            "s_cmp_eq_u64 %[m2], 0\n\t"
-            "s_mov_b64 %[m2], -1\n\t"
-            "s_cbranch_scc1 Lnc_noseed_%=\n\t"
-            "s_branch Lnc_fseed_%=\n"
-            "Lnc_kept_%=:\n\t"                              // no region to drop: the candidate may look back over the literals since
-            "s_mov_b32 %[cls], 1\n\t"                        // the last match only (avail = lit), the rest is the same
-            "s_mov_b32 %[t1], %[gap]\n\t"
-            "s_branch Lnc_avail_%=\n"
-            "Lnc_close_%=:\n\t"                             // a tracking step: close to the predicted position = not ours
-            "s_add_i32 %[t1], %[rend], %[gap]\n\t"
-            "s_sub_i32 %[t1], %[bpos], %[t1]\n\t"
-            "s_abs_i32 %[t1], %[t1]\n\t"
-            "s_cmp_le_i32 %[t1], %[MRD]\n\t"
-            "s_cbranch_scc1 Lnc_chk_%=\n\t"
-            "s_branch Lnc_distant_%=\n"
-            "Lnc_npl_%=:\n\t"
-            LZ_NC_FIX
-            "Lnc_end_%=:\n\t"
-            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-            "s_nop 4"
-            : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit),
-              [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec),
-              [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [m] "=&s"(m), [seed] "=&s"(seed),
-              [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc), [m2] "=&s"(m2),
-              [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), [w1] "=&v"(w1), [dumv] "=&v"(dumv), [qkb] "=&v"(qkb), [rk0b] "=&v"(rk0b), [rk1b] "=&v"(rk1b)
-            : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [ocl] "s"(ocl_u), [oclit] "s"(oclit_u),
-              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS),
-              [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane),
-              [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one),
-              [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64)
+            "s_mov_b32 %[cls], %[blen]\n\t" \
+            LZ_NC_COUNT \
+            "s_branch Lnc_fstart_%=\n" \
+            "Lnc_fnogo_%=:\n\t"                            /* the run ends behind entry t2 */ \
+            "s_add_i32 %[qh], %[t2], 1\n" \
+            /* the machine's state after the null event of entry t2 (see LZ_NC_COMMIT): avail = apos - fok */ \
+            "Lnc_frec_%=:\n\t" \
+            "v_readlane_b32 %[t0], %[apos], %[t2]\n\t" \
+            "v_readlane_b32 %[t1], %[alen], %[t2]\n\t" \
+            "v_readlane_b32 %[kc], %[aext], %[t2]\n\t" \
+            "s_sext_i32_i8 %[t1], %[t1]\n\t" \
+            "s_and_b32 %[kb], %[kc], 15\n\t" \
+            "s_sub_i32 %[prs], %[t0], %[kb]\n\t" \
+            "s_sub_i32 %[plit], %[t0], %[fok]\n\t" \
+            "s_sub_i32 %[plit], %[plit], %[kb]\n\t" \
+            "s_bfe_u32 %[lastlit], %[kc], 0x40014\n\t" \
+            "s_bfe_u32 %[t0], %[kc], 0x50018\n\t" \
+            "s_add_i32 %[t1], %[t1], %[t0]\n\t" \
+            "s_sub_i32 %[lastb], %[t1], %[lastlit]\n\t" \
+            "s_bfe_u32 %[t0], %[kc], 0x40004\n\t" \
+            "s_add_i32 %[lastb], %[lastb], %[t0]\n\t" \
+            "s_add_i32 %[lastlit], %[lastlit], %[kb]\n\t" \
+            "s_sub_i32 %[lastlit], %[lastlit], %[t0]\n\t" \
+            "s_mov_b32 %[pre], %[i]\n\t" \
+            "s_bitcmp0_b32 %[cls], 15\n\t" \
+            "s_cbranch_scc1 Lnc_top_%=\n"                   /* the run ended at an entry that is not GO: the general turn */ \
+            "Lnc_fseed_%=:\n\t"                             /* a seed candidate: as above (the queue head is the successor) */ \
+            "s_mov_b32 %[code], 1\n\t" \
+            LZ_NC_FIX \
+            "s_cmp_eq_u64 %[m], 0\n\t"                      /* (only steps without a k-mer) */ \
+            "s_cbranch_scc1 Lnc_snone_%=\n" \
+            /* The seed event (code = 1 here; every way out before the last line leaves it so, and seed / rk0 / rk1 / qk */ \
+            /* untouched: find_event then does the same from the round).  The simple case is found here: the first step with */ \
+            /* a seed candidate lies before the queued candidate's, ONE window position carries its msl-mer, the 64 symbols */ \
+            /* behind the msl-mer are real symbols of one strand on both sides (no lane needs a bound) and hold a mismatch: */ \
+            /* that is the event -- a seed is at least msl long and no anchor stands at its step to arbitrate with */ \
+            /* (parser.cpp:548-580, 604-606) -- adv = the step, bpos, blen = msl + the matching symbols behind. */ \
+            "Lnc_seedev_%=:\n\t" \
+            "s_ff1_i32_b64 %[t0], %[m]\n"                   /* l */ \
+            "Lnc_sdl_%=:\n\t" \
+            LZ_NC_WHY(1) \
+            "s_cmp_eq_u32 %[t0], %[gap]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 /* the queued candidate's own step: arbitration */ \
+            "v_readlane_b32 %[t1], %[qk], %[t0]\n\t"        /* the step's msl-mer */ \
+            "s_add_i32 %[t2], %[t0], %[MRD]\n\t"            /* its window: the positions idx < l + mrd */ \
+            "s_sub_i32 %[kc], %[t2], 64\n\t" \
+            "s_max_i32 %[kc], %[kc], 0\n\t" \
+            "s_min_u32 %[kb], %[t2], 64\n\t" \
+            "s_sub_i32 %[kb], 64, %[kb]\n\t"                /* (the positions of the first load beyond it leave by a shift) */ \
+            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk1]\n\t" \
+            "s_bfm_b64 %[m2], %[kc], 0\n\t" \
+            "s_and_b64 %[m2], %[m2], vcc\n\t" \
+            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk0]\n\t" \
+            "s_bcnt1_i32_b64 %[kc], %[m2]\n\t" \
+            "s_lshl_b64 vcc, vcc, %[kb]\n\t" \
+            "s_bcnt1_i32_b64 %[t1], vcc\n\t" \
+            "s_add_i32 %[t2], %[t1], %[kc]\n\t" \
+            LZ_NC_WHY(2) \
+            "s_cmp_eq_u32 %[t2], 0\n\t" \
+            "s_cbranch_scc1 Lnc_sfalse_%=\n\t"              /* no window position: the prefilter's false candidate (the bitmap holds all 80 positions) */ \
+            "s_cmp_lg_u32 %[t2], 1\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 /* several window positions: the longest, then the nearest (find_event) */ \
+            "s_ff1_i32_b64 %[t2], vcc\n\t" \
+            "s_sub_i32 %[t2], %[t2], %[kb]\n\t" \
+            "s_ff1_i32_b64 %[kc], %[m2]\n\t" \
+            "s_add_i32 %[kc], %[kc], 64\n\t" \
+            "s_cmp_lg_u32 %[t1], 0\n\t" \
+            "s_cselect_b32 %[t2], %[t2], %[kc]\n\t"         /* idx */ \
+            "s_add_i32 %[rec], %[rend], %[t2]\n\t"          /* the seed in the reference ... */ \
+            "s_add_i32 %[cls], %[i], %[t0]\n\t"             /* ... and in the query */ \
+            /* bounds: query [cls + 7, cls + 71) inside [0, Lq), Lq = qend - 33 (qend = the scan's end D - msl = Lq + mrd - msl; a pair */ \
+            /* with an N in it has qend far below zero); reference the same inside [0, L) or [rc0, rc0 + L), L = (rlim - 34) / 2 */ \
+            /* (rlim = 2 L + 3 mrd - msl + 1 - 80), rc0 = L + 2 mrd */ \
+            "s_sub_i32 %[t1], %[qend], 104\n\t" \
+            LZ_NC_WHY(3) \
+            "s_cmp_gt_i32 %[cls], %[t1]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            "s_sub_i32 %[t1], %[rlim], %[C41M]\n\t" \
+            "s_lshr_b32 %[t1], %[t1], 1\n\t" \
+            "s_add_i32 %[t2], %[rec], %[MSL64]\n\t" \
+            "s_cmp_le_i32 %[t2], %[t1]\n\t" \
+            "s_cbranch_scc1 Lnc_sok_%=\n\t" \
+            "s_add_i32 %[kb], %[t1], 80\n\t"                /* rc0 */ \
+            "s_cmp_lt_i32 %[rec], %[kb]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 /* runs from the forward strand into the pad */ \
+            "s_add_i32 %[kb], %[kb], %[t1]\n\t" \
+            "s_cmp_gt_i32 %[t2], %[kb]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n" \
+            "Lnc_sok_%=:\n\t" \
+            "s_add_i32 %[t1], %[rec], %[MSL]\n\t" \
+            "s_add_i32 %[t2], %[cls], %[MSL]\n\t" \
+            "v_add_u32_e32 %[a0], %[t1], %[lane]\n\t" \
+            "v_add_u32_e32 %[a1], %[t2], %[lane]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], 4, %[a0]\n\t" \
+            "v_lshrrev_b32_e32 %[t], 4, %[a1]\n\t" \
+            "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t" \
+            "v_lshlrev_b32_e32 %[t], 2, %[t]\n\t" \
+            "global_load_dword %[aq], %[aq], %[rt2]\n\t" \
+            "global_load_dword %[t], %[t], %[qt2]\n\t" \
+            "v_and_b32_e32 %[a0], 15, %[a0]\n\t" \
+            "v_and_b32_e32 %[a1], 15, %[a1]\n\t" \
+            "v_lshlrev_b32_e32 %[a0], 1, %[a0]\n\t" \
+            "v_lshlrev_b32_e32 %[a1], 1, %[a1]\n\t" \
+            "s_waitcnt vmcnt(0)\n\t" \
+            "v_lshrrev_b32_e32 %[aq], %[a0], %[aq]\n\t" \
+            "v_lshrrev_b32_e32 %[t], %[a1], %[t]\n\t" \
+            "v_xor_b32_e32 %[aq], %[aq], %[t]\n\t" \
+            "v_and_b32_e32 %[aq], 3, %[aq]\n\t" \
+            "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t" \
+            "s_nop 0\n\t" \
+            LZ_NC_WHY(4) \
+            "s_cmp_eq_u64 %[m], 0\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 /* 64 more symbols match: the general path measures on */ \
+            "s_ff1_i32_b64 %[blen], %[m]\n\t" \
+            "s_add_i32 %[blen], %[blen], %[MSL]\n\t" \
+            "s_mov_b32 %[ap], %[t0]\n\t" \
+            "s_mov_b32 %[bpos], %[rec]\n\t" \
+            LZ_NC_WHY(5) \
+            "s_mov_b32 %[code], 4\n\t"                      /* from here on the event is known: any way out hands it to the machine */ \
+            /* The close match itself (PairMachine::run: gap_fill, match_run, the first chunk of extend_forward), when every */ \
+            /* symbol it looks at is a real symbol of one strand and the forward extension breaks inside its first chunk. */ \
+            /* What it does to the open region (cl, clit; nl = 0 before and after): the gap's l symbols give `score` matches */ \
+            /* -- the best split's count, compare_ranges_both_ways (parser.cpp:251-374); which split wins a tie only matters to */ \
+            /* the alignment output -- and l - score literals, the match blen matches, the extension e - mm and mm. */ \
+            /*   t0 = l, rec = the seed in the reference, cls = in the query;  t1 = fq, fok = fr (behind the match) */ \
+            "s_add_i32 %[t1], %[cls], %[blen]\n\t" \
+            "s_add_i32 %[t2], %[t1], 64\n\t" \
+            "s_sub_i32 %[kb], %[qend], %[C40M]\n\t"              /* Lq */ \
+            "s_cmp_gt_i32 %[t2], %[kb]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            "s_add_i32 %[fok], %[rec], %[blen]\n\t" \
+            "s_add_i32 %[t2], %[fok], 64\n\t"               /* the reference side: [rend, fr + 64) on one strand */ \
+            "s_sub_i32 %[kb], %[rlim], %[C41M]\n\t" \
+            "s_lshr_b32 %[kb], %[kb], 1\n\t"                /* L */ \
+            "s_cmp_le_i32 %[t2], %[kb]\n\t" \
+            "s_cbranch_scc1 Lnc_hull_%=\n\t" \
+            "s_add_i32 %[kc], %[kb], 80\n\t"                /* rc0 */ \
+            "s_cmp_lt_i32 %[rend], %[kc]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            "s_add_i32 %[kc], %[kc], %[kb]\n\t" \
+            "s_cmp_gt_i32 %[t2], %[kc]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n" \
+            "Lnc_hull_%=:\n\t" \
+            /* to_scan = min(fr - rend, l), shift = l - to_scan; left diagonal (rend, i), right (fr - to_scan, i + shift) */ \
+            "s_sub_i32 %[kb], %[fok], %[rend]\n\t" \
+            "s_min_i32 %[kb], %[kb], %[t0]\n\t"             /* to_scan (0 when the seed sits at the first step) */ \
+            "s_sub_i32 %[kc], %[t0], %[kb]\n\t" \
+            "s_sub_i32 %[gap], %[fok], %[kb]\n\t"           /* right diagonal: reference start */ \
+            "s_add_i32 %[kc], %[kc], %[i]\n\t"              /*                 query start */ \
+            /* six words in flight: the word's byte address ((pos >> 4) << 2) worked out in the register the word lands in */ \
+            "v_add_u32_e32 %[rk0], %[rend], %[lane]\n\t" \
+            "v_add_u32_e32 %[rk1], %[i], %[lane]\n\t" \
+            "v_add_u32_e32 %[qk], %[gap], %[lane]\n\t" \
+            "v_add_u32_e32 %[a0], %[kc], %[lane]\n\t" \
+            "v_add_u32_e32 %[a1], %[fok], %[lane]\n\t" \
+            "v_add_u32_e32 %[aq], %[t1], %[lane]\n\t" \
+            "v_lshrrev_b32_e32 %[rk0], 4, %[rk0]\n\t" \
+            "v_lshrrev_b32_e32 %[rk1], 4, %[rk1]\n\t" \
+            "v_lshrrev_b32_e32 %[qk], 4, %[qk]\n\t" \
+            "v_lshrrev_b32_e32 %[a0], 4, %[a0]\n\t" \
+            "v_lshrrev_b32_e32 %[a1], 4, %[a1]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], 4, %[aq]\n\t" \
+            "v_lshlrev_b32_e32 %[rk0], 2, %[rk0]\n\t" \
+            "v_lshlrev_b32_e32 %[rk1], 2, %[rk1]\n\t" \
+            "v_lshlrev_b32_e32 %[qk], 2, %[qk]\n\t" \
+            "v_lshlrev_b32_e32 %[a0], 2, %[a0]\n\t" \
+            "v_lshlrev_b32_e32 %[a1], 2, %[a1]\n\t" \
+            "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t" \
+            "s_nop 0\n\t" \
+            "global_load_dword %[rk0], %[rk0], %[rt2]\n\t" \
+            "global_load_dword %[rk1], %[rk1], %[qt2]\n\t" \
+            "global_load_dword %[qk], %[qk], %[rt2]\n\t" \
+            "global_load_dword %[a0], %[a0], %[qt2]\n\t" \
+            "global_load_dword %[a1], %[a1], %[rt2]\n\t" \
+            "global_load_dword %[aq], %[aq], %[qt2]\n\t" \
+            "s_bfm_b64 %[seed], %[kb], 0\n\t"               /* the to_scan lanes of the gap's diagonals (to_scan <= 40) */ \
+            "s_waitcnt vmcnt(0)\n\t" \
+            /* left diagonal -> m = its matches */ \
+            "v_add_u32_e32 %[t], %[rend], %[lane]\n\t" \
+            "v_add_u32_e32 %[bq], %[i], %[lane]\n\t" \
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t" \
+            "v_and_b32_e32 %[t], 30, %[t]\n\t" \
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t" \
+            "v_lshrrev_b32_e32 %[rk0], %[t], %[rk0]\n\t" \
+            "v_lshrrev_b32_e32 %[rk1], %[bq], %[rk1]\n\t" \
+            "v_xor_b32_e32 %[rk0], %[rk0], %[rk1]\n\t" \
+            "v_and_b32_e32 %[rk0], 3, %[rk0]\n\t" \
+            "v_cmp_eq_u32_e64 %[m], 0, %[rk0]\n\t" \
+            /* right diagonal -> m2 */ \
+            "v_add_u32_e32 %[t], %[gap], %[lane]\n\t" \
+            "v_add_u32_e32 %[bq], %[kc], %[lane]\n\t" \
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t" \
+            "v_and_b32_e32 %[t], 30, %[t]\n\t" \
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t" \
+            "v_lshrrev_b32_e32 %[qk], %[t], %[qk]\n\t" \
+            "v_lshrrev_b32_e32 %[a0], %[bq], %[a0]\n\t" \
+            "v_xor_b32_e32 %[qk], %[qk], %[a0]\n\t" \
+            "v_and_b32_e32 %[qk], 3, %[qk]\n\t" \
+            "v_cmp_eq_u32_e64 %[m2], 0, %[qk]\n\t" \
+            /* forward chunk -> vcc = its MISmatches */ \
+            "v_add_u32_e32 %[t], %[fok], %[lane]\n\t" \
+            "v_add_u32_e32 %[bq], %[t1], %[lane]\n\t" \
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t" \
+            "v_and_b32_e32 %[t], 30, %[t]\n\t" \
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t" \
+            "v_lshrrev_b32_e32 %[a1], %[t], %[a1]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], %[bq], %[aq]\n\t" \
+            "v_xor_b32_e32 %[a1], %[a1], %[aq]\n\t" \
+            "v_and_b32_e32 %[a1], 3, %[a1]\n\t" \
+            "v_cmp_ne_u32_e32 vcc, 0, %[a1]\n\t" \
+            "s_and_b64 %[m], %[m], %[seed]\n\t"             /* Lm */ \
+            "s_and_b64 %[m2], %[m2], %[seed]\n\t"           /* Rm */ \
+            "s_mov_b64 %[seed], vcc\n\t"                    /* Bf */ \
+            /* best split: lane s scores popc(Lm below s) + popc(Rm from s on) for s <= to_scan; the maximum is what counts */ \
+            "s_bcnt1_i32_b64 %[t2], %[m2]\n\t" \
+            "s_mov_b64 vcc, %[m]\n\t" \
+            "s_nop 0\n\t" \
+            "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t" \
+            "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t" \
+            "s_mov_b64 vcc, %[m2]\n\t" \
+            "s_nop 0\n\t" \
+            "v_mbcnt_lo_u32_b32 %[bq], vcc_lo, 0\n\t" \
+            "v_mbcnt_hi_u32_b32 %[bq], vcc_hi, %[bq]\n\t" \
+            "v_add_u32_e32 %[t], %[t2], %[t]\n\t" \
+            "v_sub_u32_e32 %[t], %[t], %[bq]\n\t" \
+            "v_cmp_ge_u32_e32 vcc, %[kb], %[lane]\n\t" \
+            "s_nop 1\n\t" \
+            "v_cndmask_b32_e32 %[t], 0, %[t], vcc\n\t"      /* (a split beyond to_scan scores nothing) */ \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+            "s_nop 1\n\t" \
+            "v_readlane_b32 %[t2], %[t], 63\n\t"            /* score */ \
+            /* the forward extension's first chunk (try_extend_forward, parser.cpp:377-409; ext_lane): symbol j breaks the scan */ \
+            /* if the 15 symbols ending at it hold more than 7 mismatches, and qualifies if it and the two before it match. */ \
+            /* The window of lane j = bits [j, j + 15) of Bf << 14, as three words e0 (gap), e1 (kc), e2 (kb) */ \
+            "s_mov_b64 vcc, %[seed]\n\t" \
+            "s_lshl_b32 %[gap], vcc_lo, 14\n\t" \
+            "s_lshr_b32 %[kb], vcc_lo, 18\n\t" \
+            "s_lshl_b32 %[kc], vcc_hi, 14\n\t" \
+            "s_or_b32 %[kc], %[kc], %[kb]\n\t" \
+            "s_lshr_b32 %[kb], vcc_hi, 18\n\t" \
+            "v_mov_b32_e32 %[rk0], %[gap]\n\t" \
+            "v_mov_b32_e32 %[rk1], %[kc]\n\t" \
+            "v_mov_b32_e32 %[qk], %[kb]\n\t" \
+            "v_cmp_gt_u32_e32 vcc, 32, %[lane]\n\t" \
+            "v_alignbit_b32 %[a0], %[rk1], %[rk0], %[lane]\n\t" \
+            "v_alignbit_b32 %[a1], %[qk], %[rk1], %[lane]\n\t" \
+            "v_cndmask_b32_e32 %[a0], %[a1], %[a0], vcc\n\t" \
+            "v_and_b32_e32 %[a0], 0x7fff, %[a0]\n\t" \
+            "v_bcnt_u32_b32 %[a1], %[a0], 0\n\t" \
+            "v_and_b32_e32 %[a0], 0x7000, %[a0]\n\t" \
+            "v_cmp_lt_u32_e32 vcc, 7, %[a1]\n\t"            /* brk */ \
+            "v_cmp_eq_u32_e64 %[m], 0, %[a0]\n\t"           /* qual */ \
+            "s_nop 0\n\t" \
+            "s_cmp_eq_u64 vcc, 0\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t"                 /* no break inside the chunk: the extension runs on (the general path) */ \
+            "s_ff1_i32_b64 %[kb], vcc\n\t" \
+            "s_cmp_ge_u32 %[kb], 63\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            "s_add_i32 %[kb], %[kb], 1\n\t" \
+            "s_bfm_b64 %[m2], %[kb], 0\n\t" \
+            "s_and_b64 %[m], %[m], %[m2]\n\t"               /* qualifying symbols up to the break */ \
+            "s_mov_b32 %[kb], 0\n\t"                         /* e */ \
+            "s_mov_b32 %[kc], 0\n\t"                         /* mm */ \
+            "s_cbranch_scc0 Lnc_sext_%=\n\t" \
+            "s_flbit_i32_b64 %[kb], %[m]\n\t" \
+            "s_sub_i32 %[kb], 64, %[kb]\n\t"                /* e = the last qualifying symbol + 1 */ \
+            "s_bfm_b64 %[m2], %[kb], 0\n\t" \
+            "s_and_b64 %[m2], %[m2], %[seed]\n\t" \
+            "s_bcnt1_i32_b64 %[kc], %[m2]\n"                 /* mm: the mismatches among its e symbols */ \
+            "Lnc_sext_%=:\n\t" \
+            /* commit: the open region (the last committed event's, else the machine's) grows by the gap, the match, the extension */ \
+            "s_cmp_lg_u32 %[lastb], 0\n\t" \
+            "s_cselect_b32 %[gap], %[lastb], %[ocl]\n\t" \
+            "s_cselect_b32 %[rec], %[lastlit], %[oclit]\n\t" \
+            "s_add_i32 %[gap], %[gap], %[t2]\n\t"           /* + score */ \
+            "s_add_i32 %[gap], %[gap], %[blen]\n\t" \
+            "s_add_i32 %[gap], %[gap], %[kb]\n\t" \
+            "s_sub_i32 %[lastb], %[gap], %[kc]\n\t"         /* cl += score + blen + e - mm */ \
+            "s_add_i32 %[rec], %[rec], %[t0]\n\t" \
+            "s_sub_i32 %[rec], %[rec], %[t2]\n\t" \
+            "s_add_i32 %[lastlit], %[rec], %[kc]\n\t"       /* clit += l - score + mm */ \
+            "s_add_i32 %[i], %[t1], %[kb]\n\t" \
+            "s_add_i32 %[rend], %[fok], %[kb]\n\t" \
+            "s_mov_b32 %[pre], %[i]\n\t" \
+            "s_mov_b32 %[code], 0\n\t" \
+            "s_mov_b64 %[m2], -1\n\t" \
+            LZ_NC_COUNT \
+            "s_branch Lnc_top_%=\n" \
+            /* a false seed candidate (nine in ten of the rounds that have one): the next one; none left = the round has no seed */ \
+            /* candidate after all -- the fast turn goes on where it stood, the general turn is taken again with the flag set */ \
+            "Lnc_sfalse_%=:\n\t" \
+            "s_bitset0_b64 %[m], %[t0]\n\t" \
+            "s_cmp_eq_u64 %[m], 0\n\t" \
+            "s_cbranch_scc1 Lnc_snone_%=\n\t" \
+            "s_ff1_i32_b64 %[t0], %[m]\n\t" \
+            "s_branch Lnc_sdl_%=\n" \
+            "Lnc_snone_%=:\n\t" \
+            "s_mov_b32 %[code], 0\n\t" \
+            "s_mov_b64 %[m2], -1\n\t" \
+            "s_bitcmp1_b32 %[cls], 15\n\t" \
+            "s_cbranch_scc1 Lnc_fcont_%=\n\t" \
+            "s_mov_b64 %[m2], 0\n\t" \
+            "s_branch Lnc_top_%=\n" \
+            "Lnc_sseed_%=:\n\t"                            /* the general turn's seed candidates: known to be false if this is that second pass */ \
+            "s_cmp_eq_u64 %[m2], 0\n\t" \
+            "s_mov_b64 %[m2], -1\n\t" \
+            "s_cbranch_scc1 Lnc_noseed_%=\n\t" \
+            "s_branch Lnc_fseed_%=\n" \
+            "Lnc_kept_%=:\n\t"                              /* no region to drop: the candidate may look back over the literals since */ \
+            "s_mov_b32 %[cls], 1\n\t"                        /* the last match only (avail = lit), the rest is the same */ \
+            "s_mov_b32 %[t1], %[gap]\n\t" \
+            "s_branch Lnc_avail_%=\n" \
+            "Lnc_close_%=:\n\t"                             /* a tracking step: close to the predicted position = not ours */ \
+            "s_add_i32 %[t1], %[rend], %[gap]\n\t" \
+            "s_sub_i32 %[t1], %[bpos], %[t1]\n\t" \
+            "s_abs_i32 %[t1], %[t1]\n\t" \
+            "s_cmp_le_i32 %[t1], %[MRD]\n\t" \
+            "s_cbranch_scc1 Lnc_chk_%=\n\t" \
+            "s_branch Lnc_distant_%=\n" \
+            "Lnc_npl_%=:\n\t" \
+            LZ_NC_FIX \
+            "Lnc_end_%=:\n\t" \
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+            "s_nop 4" \
+            : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit), \
+              [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec), \
+              [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [m] "=&s"(m), [seed] "=&s"(seed), \
+              [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc), [m2] "=&s"(m2), \
+              [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), [w1] "=&v"(w1), [dumv] "=&v"(dumv), [qkb] "=&v"(qkb), [rk0b] "=&v"(rk0b), [rk1b] "=&v"(rk1b) \
+            : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [ocl] "s"(ocl_u), [oclit] "s"(oclit_u), \
+              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS), \
+              [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), \
+              [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one), \
+              [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64), [MSL] "n"(MSL), [MSL64] "n"(MSL + 64), [C41M] "n"(41 - MSL), [C40M] "n"(40 - MSL) \
             : "vcc", "scc", "memory");
+        if constexpr (CHAIN == 2) { LZ_NC_ASM(LZ_NC_WORD9) } else { LZ_NC_ASM(LZ_NC_WORD7) }
 #undef LZ_NC_LOADS_F
 #undef LZ_NC_LOADS_X
 #undef LZ_NC_ROUND_X
 #undef LZ_NC_ROUND_F
+#undef LZ_NC_ASM
+#undef LZ_NC_WORD7
+#undef LZ_NC_WORD9
 #undef LZ_NC_FTURN
 #undef LZ_NC_FIX
 #undef LZ_NC_SEEDS
@@ -1794,11 +1779,11 @@ __device__ __forceinline__ u32 xcc_id()
 // CAND: where the anchor candidates of a pair come from -- 0 = a probe per query position (refill), 1 = the wave's own
 // join with the query's sorted k-mer list (long genomes), 2 = the pair's candidate bitmap made ahead by k_pm_cand
 // (dense rows, lzani_kernels_cand.h); 1 and 2 share the bitmap form of refill (DevWave's JOIN).
-template <bool FAST, bool NFREE, bool DEFP, bool ALN, bool BK, int CAND, bool LFLT>
+template <bool FAST, bool NFREE, int DEFP, bool ALN, bool BK, int CAND, bool LFLT>
 __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int lane, u32* lds, const u32* flt)
 {
     constexpr bool JOIN = CAND != 0;
-    const Params Pk = DEFP ? Params{11, 7, 40, 40, 35, 15, 7, 3} : a.P;
+    const Params Pk = DEFP == 1 ? Params{11, 7, 40, 40, 35, 15, 7, 3} : DEFP == 2 ? Params{15, 9, 40, 40, 60, 15, 7, 3} : a.P;
     const u32 slot = a.qorder[lo];
     const u32 r = a.ref_ids[slot];
     const u64 e = a.row_off[slot] + j;
@@ -1822,9 +1807,9 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
     const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
 #ifdef LZANI_STAMPS
-    constexpr bool CHAIN = FAST && BK && DEFP && !ALN && !LFLT;     // (diagnostic build: the block kernel's stamps do not stay scalar around the hand-written loop)
+    constexpr int CHAIN = (FAST && BK && !ALN && !LFLT) ? DEFP : 0;     // (diagnostic build: the block kernel's stamps do not stay scalar around the hand-written loop)
 #else
-    constexpr bool CHAIN = FAST && BK && DEFP && !ALN;
+    constexpr int CHAIN = (FAST && BK && !ALN) ? DEFP : 0;
 #endif
     DevWave<FAST, BK, JOIN, CHAIN, LFLT> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                     qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
@@ -1889,7 +1874,7 @@ __device__ __forceinline__ u32 row_of_ticket(const u64* __restrict__ qcum, u32 r
 #ifndef LZANI_WAVES_PER_SIMD
 #define LZANI_WAVES_PER_SIMD 8                 // (occupancy experiments: the register budget of the pair kernel)
 #endif
-template <bool FAST, bool NFREE, bool DEFP, bool ALN = false, bool BK = false, int CAND = 0>
+template <bool FAST, bool NFREE, int DEFP, bool ALN = false, bool BK = false, int CAND = 0>
 __global__ void __launch_bounds__(256, LZANI_WAVES_PER_SIMD) k_pairs(PairArgs a)
 {
     const int lane = threadIdx.x & 63;

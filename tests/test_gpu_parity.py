@@ -640,6 +640,31 @@ def test_fuzz_medium_block_and_bitmap_kernels(monkeypatch):
     assert blk >= 10 and pmx >= 10, (blk, pmx)       # (both need tag words: not every random parameter set has them)
 
 
+def test_null_chain_long_genome_parameters():
+    """The hand-written null chain is compiled for two parameter sets: the defaults and --mal 15 --msl 9 --reg 60
+    (BASELINE configs[3]; the seed bitmap then works on the 14 hash bits k_kmers packs above the 9-mer).  Viral-size
+    and mid-size genomes with the second set through the bitmap form -- unrelated pairs (runs of null events), close
+    families (seed events, kept regions), N runs and ragged lengths -- against the oracle; the same data with msl 8
+    (packed k-mer words, generic kernel)."""
+    prm = dict(mal=15, msl=9, reg=60)
+    _, viral = SG.make_set(60, 91, lmin=30000, lmax=44000, fam=6, dmin=0.01, dmax=0.12)
+    withn = [s.copy() for s in viral[:40]]
+    for k in range(0, 40, 5):
+        withn[k][500 + 37 * k:500 + 37 * k + 3 + k] = 5
+    withn = [s[: 4000 + (k * 977) % (len(s) - 4000)] for k, s in enumerate(withn)]
+    _, mid = SG.make_set(12, 17, lmin=250_000, lmax=300_000, fam=3, dmin=0.005, dmax=0.05)
+    for name, data, p in (("viral", viral, prm), ("N runs, ragged", withn, prm), ("mid-size", mid, prm), ("msl 8", viral[:40], dict(mal=12, msl=8))):
+        eng = L.Engine(p)
+        eng.set_genomes(data)
+        got = eng.all2all()
+        lay = eng.layout()
+        eng.close()
+        assert lay["bitmap_launches"] == 1, (name, lay)
+        want = O.oracle_all2all(data, p, threads=16)
+        bad = np.argwhere((got != want).any(axis=2))
+        assert len(bad) == 0, (name, bad[:3].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
+
+
 def test_presence_matrix_candidates(monkeypatch):
     """Dense rows: the candidates of every pair come from per-pair bitmaps made ahead from the presence matrix of the
     batch's references (k_pm_build, k_pm_cand) and the pair kernel reads them 64 positions per lane: whole matrices

@@ -196,8 +196,11 @@ def fuzz_case_medium(st):
     mrd = st.randint(8, 64)
     prm = dict(mal=mal, msl=msl, mrd=mrd, mqd=st.randint(4, min(mrd, 64)), reg=st.randint(10, 80), aw=st.randint(4, 40),
                am=st.randint(1, 12), ar=st.randint(1, 6))
-    if st.one() < 0.3:
+    pick = st.one()
+    if pick < 0.3:
         prm = dict(DEFAULTS)
+    elif pick < 0.45:                          # the second parameter set the pair kernel folds into its code (null chain included)
+        prm = dict(DEFAULTS, **VARIANTS["long"])
     L = st.randint(8000, 70000)
     base = (st.u64(L) % np.uint64(4)).astype(np.uint8)
     seqs = [base, SG.mutate(base, 0.01 + 0.12 * st.one(), st)]
