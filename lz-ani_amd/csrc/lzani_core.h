@@ -484,6 +484,46 @@ LZ_HD u32 lane_mism32(const TextView& R, const TextView& Q, int q0, int r0)
     else valid = (u32)(~(winNf(R.nm, r0) | winNf(Q.nm, q0)) & bits_below(R.len - r0) & bits_below(Q.len - q0));
     return mm | ~valid;
 }
+// The same for 16 symbols in 32-bit arithmetic (what a record of aw <= 15 looks at: one 8-byte fetch per text and a
+// quarter of the vector instructions of the 64-bit form -- the refill spends a third of its instructions here).
+LZ_HD u32 win16f(const u64* t2, int p)
+{
+    const u32* t32 = reinterpret_cast<const u32*>(t2);               // symbol j at bits 2*(j&15) of dword j>>4
+    const u32 w = (u32)p >> 4;
+    const u32 s = ((u32)p & 15u) * 2u;
+    const u32 d0 = t32[w], d1 = t32[w + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(d1, d0, s);
+#else
+    return (u32)((((u64)d1 << 32) | d0) >> s);
+#endif
+}
+LZ_HD u32 compress_even16(u32 x)      // bits 0,2,4,.. of x -> bits 0..15
+{
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+LZ_HD u32 bits_below16(int n) { return n <= 0 ? 0u : n >= 16 ? 0xFFFFu : (1u << n) - 1u; }
+LZ_HD u32 valid_bits16(const TextView& t, int p0)
+{
+    u32 v = bits_below16(t.L - p0) & ~bits_below16(-p0);
+    if (t.rc0 != NO_RC) v |= bits_below16(t.rc0 + t.L - p0) & ~bits_below16(t.rc0 - p0);
+    return v;
+}
+// bit j (j < 16) = 1 iff Q[q0+j] does not match R[r0+j]; bits 16..31 set.  Equal to lane_mism32's low 16 bits.
+LZ_HD u32 lane_mism16(const TextView& R, const TextView& Q, int q0, int r0)
+{
+    const u32 x = win16f(R.t2, r0) ^ win16f(Q.t2, q0);
+    const u32 mm = compress_even16(x | (x >> 1));
+    u32 valid;
+    if (R.nfree && Q.nfree) valid = valid_bits16(R, r0) & valid_bits16(Q, q0);
+    else valid = (u32)(~(winNf(R.nm, r0) | winNf(Q.nm, q0)) & bits_below(R.len - r0) & bits_below(Q.len - q0)) & 0xFFFFu;
+    return mm | ~valid;
+}
 LZ_HD u32 brev32(u32 x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -524,13 +564,15 @@ LZ_HD u32 ext_qual32(u32 B, int ar)            // qual bits of a chunk's first 3
     for (int k = 1; k < a && k < 32; ++k) acc &= (Z << k) | (u32)lowmask(k);      // symbols before the start count as matches
     return acc;
 }
-LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q, int qp, int pos, int al)
+LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q, int qp, int pos, int al, bool narrow = true)
 {
     if (P.aw > 30) return EXT_REC_NONE;
     const u32 wm = (u32)lowmask(P.aw);
     u32 rec = ext_rec_none(P.aw);
     if (qp >= 32 && pos >= 32) {                                       // all 32 symbols before the match exist
-        const u32 Bb = brev32(lane_mism32(R, Q, qp - 32, pos - 32));   // bit j = symbol qp-1-j / pos-1-j
+        // bit j = symbol qp-1-j / pos-1-j; only the first aw of them are looked at
+        const u32 Bb = (narrow && P.aw <= 15) ? (brev32(lane_mism16(R, Q, qp - 16, pos - 16)) >> 16) | 0xFFFF0000u
+                                                : brev32(lane_mism32(R, Q, qp - 32, pos - 32));
         const u32 qb = ext_qual32(Bb, P.ar) & wm;
         if (popc32(Bb & wm) <= P.am) rec = qb;
         else if (P.aw > 15) rec = qb | EXT_REC_BRKB;
@@ -544,7 +586,7 @@ LZ_HD u32 null_ext_record(const Params& P, const TextView& R, const TextView& Q,
     }
     const int fq = qp + al, fr = pos + al;
     if (imin(Q.len - fq, R.len - fr) >= P.aw) {
-        const u32 Bf = lane_mism32(R, Q, fq, fr);
+        const u32 Bf = (narrow && P.aw <= 15) ? lane_mism16(R, Q, fq, fr) : lane_mism32(R, Q, fq, fr);
         if (popc32(Bf & wm) > P.am) {                                   // the scan breaks at the (am+1)-th mismatch
             u32 x = Bf & wm;
             for (int k = 0; k < P.am; ++k) x &= x - 1u;

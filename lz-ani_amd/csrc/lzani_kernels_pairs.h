@@ -582,14 +582,16 @@ struct DevWave {
             // far beyond the text)
             pos = simple ? (int)(I.bk[simple ? slot : 0u] & (u32)lowmask(I.posbits)) : 0;
         }
-        // 32 symbols of both texts from pos / qp on, as one 64-bit word each (funnel of two words, no branch)
-        const u32 wr = (u32)pos >> 5, wq = (u32)qp >> 5;
-        const int sr = (pos & 31) * 2, sq = (qp & 31) * 2;
-        const u64 r0 = R.t2[wr], r1 = R.t2[wr + 1], q0 = Q.t2[wq], q1 = Q.t2[wq + 1];
-        const u64 xr = (r0 >> sr) | ((r1 << 1) << (63 - sr)), xq = (q0 >> sq) | ((q1 << 1) << (63 - sq));
-        const u64 df = xr ^ xq;
-        const u64 d = (df | (df >> 1)) & 0x5555555555555555ULL;
-        int same = d ? (ctz64(d) >> 1) : AQ_LANE_CAP;
+        // 32 symbols of both texts from pos / qp on, as two 32-bit words each (funnel of three dwords by v_alignbit, no branch,
+        // no 64-bit shift)
+        const u32* const pr = reinterpret_cast<const u32*>(R.t2) + ((u32)pos >> 4);
+        const u32* const pq = reinterpret_cast<const u32*>(Q.t2) + ((u32)qp >> 4);
+        const u32 sr = ((u32)pos & 15u) * 2u, sq = ((u32)qp & 15u) * 2u;
+        const u32 r0 = pr[0], r1 = pr[1], r2 = pr[2], q0 = pq[0], q1 = pq[1], q2 = pq[2];
+        const u32 dlo = __builtin_amdgcn_alignbit(r1, r0, sr) ^ __builtin_amdgcn_alignbit(q1, q0, sq);
+        const u32 dhi = __builtin_amdgcn_alignbit(r2, r1, sr) ^ __builtin_amdgcn_alignbit(q2, q1, sq);
+        const u32 mlo = (dlo | (dlo >> 1)) & 0x55555555u, mhi = (dhi | (dhi >> 1)) & 0x55555555u;
+        int same = mlo ? ((int)__builtin_ctz(mlo) >> 1) : mhi ? 16 + ((int)__builtin_ctz(mhi) >> 1) : (int)AQ_LANE_CAP;
         int bound;
         if (R.nfree && Q.nfree) bound = imin(run_end(R, pos) - pos, run_end(Q, qp) - qp);
         else {

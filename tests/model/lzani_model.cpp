@@ -279,4 +279,21 @@ int model_index(const uint8_t* codes, uint32_t len, uint32_t max_len, const int3
     return 0;
 }
 
+// The null-extension record of every (query position, reference position, length) triple given, by the 16-symbol form
+// refill uses for aw <= 15 and by the 32-symbol form: returns the number of triples whose records differ (0 expected).
+int model_ext_records_agree(const uint8_t* rcodes, uint32_t rlen, const uint8_t* qcodes, uint32_t qlen, const int32_t* p8,
+                            uint32_t n, const int32_t* qp, const int32_t* rp, const int32_t* al)
+{
+    Params P{p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]};
+    if (!params_supported(P)) return -1;
+    Genome gr, gq;
+    pack_genome(gr, rcodes, (int)rlen, P);
+    pack_genome(gq, qcodes, (int)qlen, P);
+    const TextView R = gr.rview(), Q = gq.qview();
+    int bad = 0;
+    for (uint32_t k = 0; k < n; ++k)
+        bad += null_ext_record(P, R, Q, qp[k], rp[k], al[k], true) != null_ext_record(P, R, Q, qp[k], rp[k], al[k], false);
+    return bad;
+}
+
 }  // extern "C"

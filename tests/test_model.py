@@ -147,3 +147,35 @@ def test_anchor_queue_formulation():
             assert np.array_equal(got, O.oracle_all2all(seqs, prm, threads=4)), (it, prm)
             done += 1
     assert done > 100
+
+
+def test_ext_record_narrow_form_equals_wide_form():
+    """refill's null-extension records (null_ext_record) read 16 symbols per side when aw <= 15 (32-bit arithmetic); the
+    32-symbol form is the statement.  Same record for every candidate triple: random positions, positions at both ends
+    of both strands and of the query, genomes with N runs (the N-mask branch), several (aw, am, ar)."""
+    import ctypes as C
+    lib = U.model_lib()
+    st = SG.Stream(2024)
+    for it in range(12):
+        L1, L2 = st.randint(200, 3000), st.randint(200, 3000)
+        r = (st.u64(L1) % np.uint64(4)).astype(np.uint8)
+        q = SG.mutate(r, 0.05 + 0.2 * st.one(), st) if it % 2 else (st.u64(L2) % np.uint64(4)).astype(np.uint8)
+        q = np.ascontiguousarray(q).copy()
+        if it % 3 == 0:
+            a = st.randint(0, len(q) - 40); q[a:a + st.randint(1, 30)] = 5
+            r = r.copy(); a = st.randint(0, len(r) - 40); r[a:a + st.randint(1, 30)] = 5
+        prm = dict(O.DEFAULTS) if hasattr(O, "DEFAULTS") else dict(mal=11, msl=7, mrd=40, mqd=40, reg=35, aw=15, am=7, ar=3)
+        if it % 4 == 1: prm.update(aw=10, am=3, ar=5)
+        if it % 4 == 2: prm.update(aw=15, am=2, ar=1)
+        if it % 4 == 3: prm.update(aw=7, am=6, ar=3, mrd=25)
+        T = 2 * len(r) + 3 * prm["mrd"]
+        n = 4000
+        qp = np.array([st.randint(0, len(q) + prm["mrd"] - 1) for _ in range(n)], dtype=np.int32)
+        rp = np.array([st.randint(0, T - 1) for _ in range(n)], dtype=np.int32)
+        al = np.array([st.randint(0, 40) for _ in range(n)], dtype=np.int32)
+        edge = [0, 1, 15, 16, 17, 31, 32, 33, len(r) - 33, len(r) - 16, len(r) - 1, len(r), len(r) + 2 * prm["mrd"] - 1, len(r) + 2 * prm["mrd"],
+                len(r) + 2 * prm["mrd"] + 16, len(r) + 2 * prm["mrd"] + 33, T - 40, T - 17, T - 1]
+        for k, e in enumerate(edge):
+            rp[k] = max(0, min(T - 1, e)); qp[k + 32] = max(0, min(len(q) + prm["mrd"] - 1, e if e < len(q) else len(q) - (k % 40)))
+        bad = lib.model_ext_records_agree(O._ptr(r), len(r), O._ptr(q), len(q), O.params_array(prm), n, O._ptr(qp), O._ptr(rp), O._ptr(al))
+        assert bad == 0, (it, prm, bad)
