@@ -801,7 +801,7 @@ struct PairMachine {
                 // "tracking round without a seed candidate -> next plain candidate -> distant null event over a dropped
                 // short region" for as many events as it lasts: exactly the updates of the null event below, nothing
                 // else touched; what it leaves unfinished it hands back (the round done, or the event found).
-                if (trk & (lit == 0)) {
+                if ((trk & (lit == 0)) && w.chain_covers(i)) {      // (not where the scan has jumped over the queue: related stretches)
                     int last_cl = 0, last_clit = 0, add_tm = 0, add_tl = 0, add_tc = 0;
 #if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
                     w.cycles_mark(-1);                                 // wave cycles by what the chain handed back: closes the open interval

@@ -779,6 +779,9 @@ struct DevWave {
     // at a match_distant factor, into add_tm / add_tl / add_tc (the machine adds them to its totals), and the candidate
     // looks back over the literals since the last match only.  Wait states of gfx950 are placed by hand
     // (VALU-written mask -> VALU use: 2; lane select / VMEM base written by a VALU: the prologue is long enough).
+    // The chain has nothing to work with where the scan stands beyond everything detected so far (an extension has moved
+    // over the queue: a related stretch, find_event's light rounds): it would leave at once, nothing touched.
+    __device__ __forceinline__ bool chain_covers(int i) const { return scan_pos >= i; }
     __device__ __forceinline__ int null_chain(int& i, int& r_end, int& prev_rs, int& prev_re, int& pre_lit, int& last_cl,
                                               int& last_clit, int& adv, int& bpos, int& blen, int open_cl, int open_clit,
                                               int& add_tm, int& add_tl, int& add_tc)
