@@ -328,19 +328,26 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, Filter& flt, P
             if (devs.empty()) devs.push_back(P.device);
         }
         lzani_group* grp = nullptr;
+        const auto t_a = chrono::steady_clock::now();
         int rc = E.group_create(&P.lz, (uint32_t)devs.size(), devs.data(), &grp);
         if (rc != LZANI_OK) {
             cerr << "LZ matching failed: lzani_group_create failed with code " << rc << ": " << E.group_last_error(nullptr) << endl;
             return false;
         }
+        const auto t_b = chrono::steady_clock::now();
         rc = E.group_set_genomes(grp, n, ptr.data(), len.data());
+        const auto t_c = chrono::steady_clock::now();
         if (rc == LZANI_OK) rc = E.group_run_rows(grp, n, ref_ids.data(), T.row_off.data(), qids, T.res.data());
+        if (P.verbosity >= 2)
+            cerr << "engine: create " << chrono::duration<double>(t_b - t_a).count() << " s, genomes to the device " << chrono::duration<double>(t_c - t_b).count()
+                 << " s, matching " << chrono::duration<double>(chrono::steady_clock::now() - t_c).count() << " s\n";
         if (rc != LZANI_OK) { cerr << "LZ matching failed: " << E.group_last_error(grp) << endl; E.group_destroy(grp); return false; }
         if (P.verbosity >= 2)
             for (int d = 0; d < (int)devs.size(); ++d) {
                 lzani_timing t; double gather = 0;
                 if (E.group_get_timing(grp, (uint32_t)d, &t, &gather) == LZANI_OK)
-                    cerr << "GPU " << devs[d] << ": " << t.pairs << " pairs, index " << t.index_ms << " ms, pair kernel " << t.pairs_ms << " ms"
+                    cerr << "GPU " << devs[d] << ": " << t.pairs << " pairs, index " << t.index_ms << " ms, k-mer words " << t.kmers_ms
+                         << " ms, candidate stage " << t.cand_ms << " ms, pair kernel " << t.pairs_ms << " ms"
                          << (d == 0 && devs.size() > 1 ? ", gather " + to_string(gather) + " ms" : string()) << "\n";
             }
         E.group_destroy(grp);
@@ -393,7 +400,8 @@ static bool do_matching(const Engine& E, const vector<Genome>& g, Filter& flt, P
             if (P.verbosity >= 2) {
                 lzani_timing t;
                 if (E.get_timing(ctx, &t) == LZANI_OK)
-                    cerr << "GPU " << P.device + d << ": " << t.pairs << " pairs, index " << t.index_ms << " ms, pair kernel " << t.pairs_ms << " ms\n";
+                    cerr << "GPU " << P.device + d << ": " << t.pairs << " pairs, index " << t.index_ms << " ms, k-mer words " << t.kmers_ms
+                         << " ms, candidate stage " << t.cand_ms << " ms, pair kernel " << t.pairs_ms << " ms\n";
             }
         }
         E.destroy(ctx);
