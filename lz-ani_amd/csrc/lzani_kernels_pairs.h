@@ -33,7 +33,7 @@ __device__ __forceinline__ u32 rep4(u32 b) { return __builtin_amdgcn_perm(b, b, 
 
 template <bool FAST, bool BK = false, bool JOIN = false, int CHAIN = 0, bool LFLT = false>
 struct DevWave {
-    static constexpr bool NULL_CHAIN = CHAIN != 0;      // (1 = the default parameters, 2 = mal 15, msl 9, reg 60: see pair_body)
+    static constexpr bool NULL_CHAIN = CHAIN != 0;      // (1 = the default parameters, 3 = the same in a kernel for genomes without N, 2 = mal 15, msl 9, reg 60: see pair_body)
     const Params& P;
     TextView R, Q;
     IndexView I;
@@ -648,7 +648,10 @@ struct DevWave {
     __device__ __forceinline__ void chain_classes()
     {
         enum { MQD = 40, MRD = 40, MSL = CHAIN == 2 ? 9 : 7, REG = CHAIN == 2 ? 60 : 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };
-        const int ilim = imin(scan_pos, iend) - NT, rlim = R.len - MSL + 1 - WIN;
+        // (N-free pair: the rounds of the fast turns -- the ones a GO bit lets through -- only ever see real msl-mers: all 64
+        // query lanes, all 80 window positions inside one strand; their address arithmetic then needs no clamp, LZ_NC_WORD7N)
+        constexpr bool nf = CHAIN == 3;             // (the default parameters in a kernel for genomes without N)
+        const int ilim = imin(imin(scan_pos, iend) - NT, nf ? Q.L - MSL + 1 - 64 : iend), rlim = R.len - MSL + 1 - WIN;
         const int len = a_len;
         const bool plain = len > 0;
         const u32 rec = a_ext;
@@ -657,7 +660,8 @@ struct DevWave {
         const int end = a_pos + t2, rend = pos + t2;
         const bool both = (rec & (EXT_REC_FWDK | EXT_REC_BRKB)) == (u32)(EXT_REC_FWDK | EXT_REC_BRKB);
         const bool cap = plain & both & (imin(a_pos, pos) >= AW);                      // as a successor
-        const bool pred = plain & both & (end <= ilim) & (rend <= rlim) & (t2 + (int)(rec & 15u) < REG);   // as a predecessor
+        const bool rwin = !nf | (rend + WIN <= R.L - MSL + 1) | ((rend >= R.rc0) & (rend + WIN <= R.rc0 + R.L - MSL + 1));
+        const bool pred = plain & both & (end <= ilim) & (rend <= rlim) & rwin & (t2 + (int)(rec & 15u) < REG);   // as a predecessor
         const int mine = (int)((u32)pos | (cap ? 0x80000000u : 0u));
         int succ = 64, s_pos = 0, s_u = 0;
 #pragma unroll
@@ -843,6 +847,10 @@ struct DevWave {
             "v_lshlrev_b32_e32 %[" T "], %[" K "], %[one]\n\t" \
             "v_min_u32_e32 %[" A "], %[dumv], %[" A "]\n\t" \
             "v_lshl_add_u32 %[" A "], %[" A "], 2, %[ldsb]\n\t"
+#define LZ_NC_WORD7N(A, T, K) \
+            "v_lshrrev_b32_e32 %[" A "], 5, %[" K "]\n\t" \
+            "v_lshlrev_b32_e32 %[" T "], %[" K "], %[one]\n\t" \
+            "v_lshl_add_u32 %[" A "], %[" A "], 2, %[ldsb]\n\t"
 #define LZ_NC_WORD9(A, T, K) \
             "v_lshrrev_b32_e32 %[" A "], 23, %[" K "]\n\t" \
             "v_lshrrev_b32_e32 %[" T "], 18, %[" K "]\n\t" \
@@ -863,7 +871,7 @@ struct DevWave {
             "v_cmp_ne_u32_e64 %[seed], 0, %[aq]\n\t"
 #define LZ_NC_ROUND_F(WORD) LZ_NC_ROUND_X(WORD, "s_waitcnt vmcnt(0)", "qk", "rk0", "rk1")
         // one fast turn (see Lnc_fast)
-#define LZ_NC_FTURN(WORD, P, N, IC, IN, RN, CQ, C0, C1, NQ, N0, N1, SFX) \
+#define LZ_NC_FTURN(WORDF, P, N, IC, IN, RN, CQ, C0, C1, NQ, N0, N1, SFX) \
             "Lnc_fturn" SFX "_%=:\n\t" \
             "s_bitcmp0_b32 %[" P "], 15\n\t" \
             "s_cbranch_scc1 Lnc_fnogo" SFX "_%=\n\t" \
@@ -876,7 +884,7 @@ struct DevWave {
             "s_add_i32 %[" IN "], %[ap], %[t0]\n\t" \
             "s_add_i32 %[" RN "], %[bpos], %[t0]\n\t" \
             LZ_NC_LOADS_X(IN, RN, NQ, N0, N1) \
-            LZ_NC_ROUND_X(WORD, "s_waitcnt vmcnt(3)", CQ, C0, C1) \
+            LZ_NC_ROUND_X(WORDF, "s_waitcnt vmcnt(3)", CQ, C0, C1) \
             LZ_NC_SEEDS \
             "s_cbranch_scc1 Lnc_frec" SFX "_%=\n\t"         /* a seed candidate: the state first, then the seed event */ \
             "s_mov_b32 %[t2], %[qh]\n\t" \
@@ -925,7 +933,7 @@ struct DevWave {
         const int qend = __builtin_amdgcn_readfirstlane((R.nfree && Q.nfree) ? iend : -(1 << 30));
         // (the machine's accumulators may live in vector registers -- they come out of popcounts: as scalars for the loop)
         const int ocl_u = __builtin_amdgcn_readfirstlane(open_cl), oclit_u = __builtin_amdgcn_readfirstlane(open_clit);
-#define LZ_NC_ASM(WORD) \
+#define LZ_NC_ASM(WORD, WORDF) \
         asm volatile( \
             "s_mov_b32 %[code], 0\n\t" \
             "s_mov_b32 %[lastb], 0\n\t" \
@@ -1073,8 +1081,8 @@ struct DevWave {
             /* before it waits for its own, so the loads of one turn fly during the LDS phase of the turn before.  A turn that */ \
             /* ends the run (no GO, a seed candidate) leaves the request behind; what leaves the second turn puts the */ \
             /* registers back: cls the committed entry's word, blen the successor's, i / rend the round's, qk / rk0 / rk1 its k-mers. */ \
-            LZ_NC_FTURN(WORD, "cls", "blen", "i", "t1", "kb", "qk", "rk0", "rk1", "qkb", "rk0b", "rk1b", "") \
-            LZ_NC_FTURN(WORD, "blen", "cls", "t1", "i", "rend", "qkb", "rk0b", "rk1b", "qk", "rk0", "rk1", "2") \
+            LZ_NC_FTURN(WORDF, "cls", "blen", "i", "t1", "kb", "qk", "rk0", "rk1", "qkb", "rk0b", "rk1b", "") \
+            LZ_NC_FTURN(WORDF, "blen", "cls", "t1", "i", "rend", "qkb", "rk0b", "rk1b", "qk", "rk0", "rk1", "2") \
             "s_branch Lnc_fturn_%=\n" \
             "Lnc_fnogo2_%=:\n\t" \
             "s_mov_b32 %[i], %[t1]\n\t" \
@@ -1447,13 +1455,16 @@ struct DevWave {
               [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one), \
               [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64), [MSL] "n"(MSL), [MSL64] "n"(MSL + 64), [C41M] "n"(41 - MSL), [C40M] "n"(40 - MSL) \
             : "vcc", "scc", "memory");
-        if constexpr (CHAIN == 2) { LZ_NC_ASM(LZ_NC_WORD9) } else { LZ_NC_ASM(LZ_NC_WORD7) }
+        if constexpr (CHAIN == 2) { LZ_NC_ASM(LZ_NC_WORD9, LZ_NC_WORD9) }
+        else if constexpr (CHAIN == 3) { LZ_NC_ASM(LZ_NC_WORD7, LZ_NC_WORD7N) }      // (N-free by instantiation: see chain_classes)
+        else { LZ_NC_ASM(LZ_NC_WORD7, LZ_NC_WORD7) }
 #undef LZ_NC_LOADS_F
 #undef LZ_NC_LOADS_X
 #undef LZ_NC_ROUND_X
 #undef LZ_NC_ROUND_F
 #undef LZ_NC_ASM
 #undef LZ_NC_WORD7
+#undef LZ_NC_WORD7N
 #undef LZ_NC_WORD9
 #undef LZ_NC_FTURN
 #undef LZ_NC_FIX
@@ -1815,9 +1826,9 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
     const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
 #ifdef LZANI_STAMPS
-    constexpr int CHAIN = (FAST && BK && !ALN && !LFLT) ? DEFP : 0;     // (diagnostic build: the block kernel's stamps do not stay scalar around the hand-written loop)
+    constexpr int CHAIN = (FAST && BK && !ALN && !LFLT) ? (DEFP == 1 && NFREE ? 3 : DEFP) : 0;     // (diagnostic build: the block kernel's stamps do not stay scalar around the hand-written loop)
 #else
-    constexpr int CHAIN = (FAST && BK && !ALN) ? DEFP : 0;
+    constexpr int CHAIN = (FAST && BK && !ALN) ? (DEFP == 1 && NFREE ? 3 : DEFP) : 0;
 #endif
     DevWave<FAST, BK, JOIN, CHAIN, LFLT> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                     qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
