@@ -933,8 +933,16 @@ struct DevWave {
         const int qend = __builtin_amdgcn_readfirstlane((R.nfree && Q.nfree) ? iend : -(1 << 30));
         // (the machine's accumulators may live in vector registers -- they come out of popcounts: as scalars for the loop)
         const int ocl_u = __builtin_amdgcn_readfirstlane(open_cl), oclit_u = __builtin_amdgcn_readfirstlane(open_clit);
+#ifdef LZANI_CHAIN_PRIO                             // (experiment: the loop's waves ahead of the others in the issue arbitration)
+#define LZ_NC_PRIO_ON "s_setprio 2\n\t"
+#define LZ_NC_PRIO_OFF "s_setprio 0\n\t"
+#else
+#define LZ_NC_PRIO_ON
+#define LZ_NC_PRIO_OFF
+#endif
 #define LZ_NC_ASM(WORD, WORDF) \
         asm volatile( \
+            LZ_NC_PRIO_ON \
             "s_mov_b32 %[code], 0\n\t" \
             "s_mov_b32 %[lastb], 0\n\t" \
             "s_mov_b32 %[lastlit], 0\n\t" \
@@ -1443,6 +1451,7 @@ struct DevWave {
             LZ_NC_FIX \
             "Lnc_end_%=:\n\t" \
             "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+            LZ_NC_PRIO_OFF \
             "s_nop 4" \
             : LZ_NC_COUNT_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [qh] "+s"(qh), [prs] "+s"(prev_rs), [pre] "+s"(prev_re), [plit] "+s"(pre_lit), \
               [code] "=&s"(code), [ap] "=&s"(ap), [bpos] "=&s"(bpos), [blen] "=&s"(blen), [lastb] "=&s"(last_cl), [lastlit] "=&s"(last_clit), [rec] "=&s"(rec), \
