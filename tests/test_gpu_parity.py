@@ -895,6 +895,64 @@ def test_device_group_single_process(monkeypatch):
         grp.close()
 
 
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()           # (counts devices without initialising the GPU)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: RCCL over xGMI (the one-GPU box rehearses the same paths on device 0)")
+def test_device_group_two_gpus_rccl():
+    """The group on two real devices: shards move by grouped ncclSend / ncclRecv from a single thread across the
+    communicators of ncclCommInitAll.  Dense rows (cyclic deal) and filtered rows of very unequal sizes (LPT) against
+    the single-context run."""
+    _, seqs = SG.make_set(41, 29, lmin=3000, lmax=7000, fam=6)
+    n = len(seqs)
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    want = eng.all2all()
+    st = SG.Stream(78)
+    rr, off, q = [], [0], []
+    for k in range(60):
+        r = st.randint(0, n - 1)
+        cnt = 0 if k % 7 == 3 else (35 if k % 9 == 0 else st.randint(1, 4))
+        rr.append(r)
+        for _ in range(cnt):
+            x = st.randint(0, n - 1)
+            q.append(x if x != r else (x + 1) % n)
+        off.append(len(q))
+    want_rows = eng.run_rows(np.array(rr, dtype=np.uint32), np.array(off, dtype=np.uint64), np.array(q, dtype=np.uint32))
+    eng.close()
+    grp = L.Group(None, (0, 1))
+    grp.set_genomes(seqs)
+    ref_ids, row_off = L.dense_rows(n)
+    assert np.array_equal(grp.run_rows(ref_ids, row_off, None), want[~np.eye(n, dtype=bool)])
+    assert np.array_equal(grp.run_rows(rr, off, q), want_rows)
+    assert all(grp.timing(d)["pairs"] > 0 for d in range(2))
+    grp.close()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: the library's own communicator (ncclCommInitRank + ncclAllGather) at N = 2")
+def test_bench_two_ranks_library_collective():
+    """bench.py --gpus 2 --collective lzani under torch.distributed.run, one rank per GPU: what the default stays away from
+    (--collective torch) until this has passed on hardware."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    for coll in ("lzani", "torch"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+               "--genomes", "300", "--seed", "9", "--slab", "50", "--lmin", "3000", "--lmax", "5000", "--collective", coll]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (coll, p.stderr[-2000:])
+        d = json.loads([ln for ln in p.stdout.split("\n") if ln.startswith("{")][0])
+        assert d["n_gpus"] == 2 and d["parity_on_last_slab"] == "bit-exact", coll
+
+
 def test_rccl_communicator_single_rank():
     """lzani_comm_* with a one-rank communicator: the library's own RCCL calls (ncclGetUniqueId, ncclCommInitRank,
     ncclAllGather, grouped ncclSend/ncclRecv path of the root) run on this box; the N > 1 data movement is covered
