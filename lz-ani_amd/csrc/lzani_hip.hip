@@ -25,6 +25,9 @@ __device__ unsigned long long g_stamp_acc[8];
 #ifdef LZANI_CHAIN_STATS
 __device__ unsigned long long g_chain_stats[24];
 #endif
+#ifdef LZANI_PHASE_TIME
+__device__ unsigned long long g_phase_time[4];
+#endif
 
 int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_t n, int begin_bit, int end_bit,
                     void* tmp, size_t* tmp_bytes, hipStream_t stream);      // lzani_sort.hip (hipCUB radix sort)
@@ -852,6 +855,16 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         fprintf(stderr, "\n");
         unsigned long long z[8] = {0};
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof z));
+    }
+#endif
+#ifdef LZANI_PHASE_TIME
+    {
+        unsigned long long acc[4], z[4] = {0};
+        HIPCHK(c, hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_phase_time), sizeof acc));
+        if (acc[3])
+            fprintf(stderr, "[lzani phase] pairs=%llu, s_memtime ticks per pair: whole pair %.0f, inside the null chain %.0f (%.1f %%), inside refill %.0f (%.1f %%)\n",
+                    acc[3], (double)acc[0] / acc[3], (double)acc[1] / acc[3], 100.0 * acc[1] / acc[0], (double)acc[2] / acc[3], 100.0 * acc[2] / acc[0]);
+        HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_phase_time), z, sizeof z));
     }
 #endif
 #ifdef LZANI_CHAIN_STATS

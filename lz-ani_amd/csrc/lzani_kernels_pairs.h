@@ -75,6 +75,15 @@ struct DevWave {
         stc_t0 = t;
     }
 #endif
+#ifdef LZANI_PHASE_TIME                             // slim diagnostic build: wave cycles inside the null chain / inside refill / per pair
+    unsigned long long pt_chain = 0, pt_refill = 0;
+    static __device__ __forceinline__ unsigned long long pt_now()
+    {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        return t;
+    }
+#endif
     // null_chain found the queue short of what it needs -- empty, or ending inside the tracking steps of i -- with more
     // of the pair's bitmap to read: the next find_event call only refills (from i, if queued candidates are left)
     bool refill_only = false;
@@ -459,6 +468,9 @@ struct DevWave {
         const int stamp_sv = cur;
         stamp(2);
 #endif
+#ifdef LZANI_PHASE_TIME
+        const unsigned long long pt_r0 = pt_now();
+#endif
         u32* const cq = bitmap;                                 // (all zero again when refill returns)
         const int tb = I.kb - I.dirbits;
         scan_pos = imax(scan_pos, from);
@@ -626,6 +638,10 @@ struct DevWave {
             a_len = ml; a_ref = (u32)mr; a_ext = (u32)mx;
         }
         if constexpr (CHAIN) chain_classes();
+#ifdef LZANI_PHASE_TIME
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        pt_refill += pt_now() - pt_r0;
+#endif
 #ifdef LZANI_STAMPS
         stamp(stamp_sv);
 #endif
@@ -1464,9 +1480,15 @@ struct DevWave {
               [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one), \
               [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64), [MSL] "n"(MSL), [MSL64] "n"(MSL + 64), [C41M] "n"(41 - MSL), [C40M] "n"(40 - MSL) \
             : "vcc", "scc", "memory");
+#ifdef LZANI_PHASE_TIME
+        const unsigned long long pt_t0 = pt_now();
+#endif
         if constexpr (CHAIN == 2) { LZ_NC_ASM(LZ_NC_WORD9, LZ_NC_WORD9) }
         else if constexpr (CHAIN == 3) { LZ_NC_ASM(LZ_NC_WORD7, LZ_NC_WORD7N) }      // (N-free by instantiation: see chain_classes)
         else { LZ_NC_ASM(LZ_NC_WORD7, LZ_NC_WORD7) }
+#ifdef LZANI_PHASE_TIME
+        pt_chain += pt_now() - pt_t0;
+#endif
 #undef LZ_NC_LOADS_F
 #undef LZ_NC_LOADS_X
 #undef LZ_NC_ROUND_X
@@ -1868,7 +1890,19 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     }
     if (!JOIN)
 #endif
+#ifdef LZANI_PHASE_TIME
+    const unsigned long long pt_p0 = w.pt_now();
+#endif
     m.run(res);
+#ifdef LZANI_PHASE_TIME
+    {
+        const unsigned long long pt_all = w.pt_now() - pt_p0;
+        atomicAdd(&g_phase_time[0], lane == 0 ? pt_all : 0ULL);
+        atomicAdd(&g_phase_time[1], lane == 0 ? w.pt_chain : 0ULL);
+        atomicAdd(&g_phase_time[2], lane == 0 ? w.pt_refill : 0ULL);
+        atomicAdd(&g_phase_time[3], lane == 0 ? 1ULL : 0ULL);
+    }
+#endif
 #ifdef LZANI_CHAIN_STATS
     for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[k], lane == 0 ? (unsigned long long)w.st[k] : 0ULL);
     for (int k = 0; k < 4; ++k) atomicAdd(&g_chain_stats[8 + k], lane == 0 ? w.stc[k] : 0ULL);
