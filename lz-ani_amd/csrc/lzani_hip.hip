@@ -523,9 +523,17 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     u64 cb_words = 0;                                        // 32-bit words of one pair's candidate bitmap
     u32 pm_tiles = 0, pm_group = PM_GROUP;
     const int pm_bits = std::min(c->geo.kb, 30);             // exact up to mal 15: the mixer is a bijection on the key bits
+    bool use_join = false;
+    std::vector<u32> bstart;
+    // Two attempts: the candidate-bitmap form first where it applies; if its buffers (matrix, pair table, bitmaps) cannot be
+    // had after all -- the sizing below is an estimate, and hipMalloc may fail on a fragmented heap -- they are released
+    // and the run falls back to the probe / join form, which needs none of them.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    pm = false;
     u32 want_rows = n_rows;
     u64 pm_cap_pairs = 0;                                    // pairs whose bitmaps a batch may hold
-    {
+    bool pm_nomem = false;
+    if (attempt == 0) {
         const char* e = getenv("LZANI_PM");
         const char* mn = getenv("LZANI_PM_MIN_ROWS");
         const char* mb = getenv("LZANI_PM_MAX_BYTES");
@@ -554,7 +562,10 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             const size_t per_slot = (size_t)4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride) + (c->sort_build ? (size_t)16 * c->Tmax + 16 : 0);
             size_t free_b = 0, total_b = 0;
             HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-            const size_t pool = free_b + (size_t)c->slots * per_slot + c->pm_cbits_bytes + c->pm_bytes + c->pm_pidx_bytes;   // what this run may lay out anew
+            // what this run may lay out anew: the free memory and what the context holds from earlier runs -- ITS slabs
+            // included, which is why slabs larger than this run wants are released below (ensure_slabs never shrinks them:
+            // an earlier run with sparse rows may have grown them to 60 % of the memory)
+            const size_t pool = free_b + (size_t)c->slots * per_slot + c->pm_cbits_bytes + c->pm_bytes + c->pm_pidx_bytes;
             const size_t cap = mb ? (size_t)strtoull(mb, nullptr, 10) : std::min((size_t)64 << 30, total_b / 4);
             const double room = pool * 0.85 - (double)m_bytes - (double)x_bytes;
             u64 fit = room > 0 ? (u64)(room / ((double)per_slot + avg_row * (double)per_pair)) : 0;     // rows: a slab + its pairs' bitmaps each
@@ -564,26 +575,31 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             if (fit < std::min<u32>(8, n_rows) || pm_cap_pairs < max_row) pm = false;    // (a genome set this large: the probe / join form, batch by batch)
             else {
                 want_rows = (u32)fit;
+                if (c->slots > want_rows) free_slabs(c);                         // (counted as available above)
                 if (c->pm_bytes < m_bytes) {
                     hipFree(c->d_pm); c->d_pm = nullptr; c->pm_bytes = 0;
-                    HIPCHK(c, hipMalloc(&c->d_pm, m_bytes));
-                    c->pm_bytes = m_bytes;
+                    if (hipMalloc(&c->d_pm, m_bytes) != hipSuccess) { (void)hipGetLastError(); c->d_pm = nullptr; pm_nomem = true; }
+                    else c->pm_bytes = m_bytes;
                 }
-                if (c->pm_pidx_bytes < x_bytes) {
+                if (!pm_nomem && c->pm_pidx_bytes < x_bytes) {
                     hipFree(c->d_pm_pidx); c->d_pm_pidx = nullptr; c->pm_pidx_bytes = 0;
-                    HIPCHK(c, hipMalloc(&c->d_pm_pidx, x_bytes));
-                    c->pm_pidx_bytes = x_bytes;
+                    if (hipMalloc(&c->d_pm_pidx, x_bytes) != hipSuccess) { (void)hipGetLastError(); c->d_pm_pidx = nullptr; pm_nomem = true; }
+                    else c->pm_pidx_bytes = x_bytes;
                 }
             }
         }
     }
-    const bool use_join = c->join_mode && !pm;
+    if (pm_nomem) { TRACE("candidate bitmaps: no memory for the matrix / pair table, falling back"); free_pm(c); continue; }
+    use_join = c->join_mode && !pm;
     if (use_join) { rc = ensure_join(c); if (rc) return rc; }          // (before the slabs are sized: they take 60 % of what is left)
     rc = ensure_slabs(c, want_rows);
-    if (rc) return rc;
+    if (rc) {
+        if (pm && rc == LZANI_ERR_NOMEM) { free_pm(c); continue; }
+        return rc;
+    }
     // Batches: as many consecutive rows as there are index slabs -- and, with candidate bitmaps, as their pairs' bitmaps
     // may take.
-    std::vector<u32> bstart(1, 0);
+    bstart.assign(1, 0);
     {
         u32 rows = 0, rows_cap = c->slots;
         u64 pairs = 0, most = 0;
@@ -600,13 +616,22 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         bstart.push_back(n_rows);
         most = std::max(most, pairs);
         if (pm) {
-            const size_t need = (size_t)most * cb_words * 4;
+            size_t need = (size_t)most * cb_words * 4;
+            if (const char* fe = getenv("LZANI_PM_FAIL_CBITS")) if (*fe == '1') need = (size_t)1 << 60;     // tests: the fallback below
             if (c->pm_cbits_bytes < need) {
                 hipFree(c->d_pm_cbits); c->d_pm_cbits = nullptr; c->pm_cbits_bytes = 0;
-                HIPCHK(c, hipMalloc(&c->d_pm_cbits, need));
+                if (hipMalloc(&c->d_pm_cbits, need) != hipSuccess) {
+                    (void)hipGetLastError();
+                    c->d_pm_cbits = nullptr;
+                    TRACE("candidate bitmaps: no memory for %zu bytes of bitmaps, falling back", need);
+                    free_pm(c);
+                    continue;
+                }
                 c->pm_cbits_bytes = need;
             }
         }
+    }
+    break;
     }
     const u32 bs = c->slots;
 

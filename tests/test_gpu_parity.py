@@ -708,6 +708,47 @@ def test_presence_matrix_candidates(monkeypatch):
     assert np.array_equal(got, want)
 
 
+def test_presence_matrix_after_sparse_run_and_allocation_fallback(monkeypatch):
+    """One Engine, a sparse run with many rows first (its index slabs grow to one per row), then a dense run: the
+    bitmap form counts the context's slabs as available, so slabs larger than it wants are released before it sizes its
+    buffers.  And a failed allocation of the candidate bitmaps is not an error: the run falls back to the
+    probe form (LZANI_PM_FAIL_CBITS=1 makes the request unsatisfiable)."""
+    _, seqs = SG.make_set(150, 47, lmin=17000, lmax=20000, fam=10)
+    n = len(seqs)
+    want = O.oracle_all2all(seqs, None, threads=16)
+    eng = L.Engine()
+    eng.set_genomes(seqs)
+    # sparse rows: every genome as a reference with two queries each -> 150 slabs, probe form
+    rr = np.arange(n, dtype=np.uint32)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2)
+    q = np.array([[(r + 1) % n, (r + 77) % n] for r in range(n)], dtype=np.uint32).reshape(-1)
+    got = eng.run_rows(rr, off, q)
+    lay = eng.layout()
+    assert lay["bitmap_launches"] == 0 and lay["slots"] == n, lay
+    for r in range(n):
+        assert tuple(got[2 * r]) == tuple(want[r, (r + 1) % n]) and tuple(got[2 * r + 1]) == tuple(want[r, (r + 77) % n])
+    # dense rows of a few references on the same context: bitmap form, slabs shrunk to what it wants
+    monkeypatch.setenv("LZANI_PM_MIN_ROWS", "1")
+    ref_ids, row_off = L.dense_rows(n, np.arange(40, dtype=np.uint32))
+    got = eng.run_rows(ref_ids, row_off, None).reshape(40, n - 1, 3)
+    lay = eng.layout()
+    assert lay["bitmap_launches"] == 1 and lay["slots"] == 40, lay
+    for r in range(40):
+        assert np.array_equal(got[r], want[r, np.arange(n) != r]), r
+    # the same rows with the bitmaps' allocation failing: fallback, same results
+    monkeypatch.setenv("LZANI_PM_FAIL_CBITS", "1")
+    got = eng.run_rows(ref_ids, row_off, None).reshape(40, n - 1, 3)
+    lay = eng.layout()
+    assert lay["bitmap_launches"] == 0, lay
+    monkeypatch.delenv("LZANI_PM_FAIL_CBITS")
+    for r in range(40):
+        assert np.array_equal(got[r], want[r, np.arange(n) != r]), r
+    # and back again
+    assert np.array_equal(eng.all2all(), want)
+    assert eng.layout()["bitmap_launches"] == 1
+    eng.close()
+
+
 def test_presence_matrix_with_query_lists():
     """Candidate bitmaps for rows with query LISTS that are dense where they are: the row x column blocks a host cuts
     a dense all2all into so that it can emit finished rows while the GPU works on the next block (lz-ani does) --
@@ -895,16 +936,23 @@ def test_device_group_single_process(monkeypatch):
         grp.close()
 
 
-def _n_gpus():
-    import torch
-    return torch.cuda.device_count()           # (counts devices without initialising the GPU)
+def _need_two_gpus(why):
+    """Skip unless two GPUs are visible.  Asked inside the test, not in a skipif decorator: collecting the module (also
+    with the gpu tests deselected, also on a box without torch) must not start the HIP runtime."""
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:
+        n = 0
+    if n < 2:
+        pytest.skip(why)
 
 
-@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: RCCL over xGMI (the one-GPU box rehearses the same paths on device 0)")
 def test_device_group_two_gpus_rccl():
     """The group on two real devices: shards move by grouped ncclSend / ncclRecv from a single thread across the
     communicators of ncclCommInitAll.  Dense rows (cyclic deal) and filtered rows of very unequal sizes (LPT) against
     the single-context run."""
+    _need_two_gpus("needs two GPUs: RCCL over xGMI (the one-GPU box rehearses the same paths on device 0)")
     _, seqs = SG.make_set(41, 29, lmin=3000, lmax=7000, fam=6)
     n = len(seqs)
     eng = L.Engine()
@@ -931,10 +979,10 @@ def test_device_group_two_gpus_rccl():
     grp.close()
 
 
-@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: the library's own communicator (ncclCommInitRank + ncclAllGather) at N = 2")
 def test_bench_two_ranks_library_collective():
     """bench.py --gpus 2 --collective lzani under torch.distributed.run, one rank per GPU: what the default stays away from
     (--collective torch) until this has passed on hardware."""
+    _need_two_gpus("needs two GPUs: the library's own communicator (ncclCommInitRank + ncclAllGather) at N = 2")
     import json
     import socket
     import subprocess

@@ -107,7 +107,7 @@ def make_set_cached(n, seed, cache_dir=None, **kw):
     per-user directory (LZANI_SYNTH_CACHE, else $XDG_CACHE_HOME/lzani_synth, else ~/.cache/lzani_synth, else a
     uid-suffixed directory under /tmp); an entry carries a checksum of its codes and is regenerated when it does not
     verify."""
-    import os, zlib
+    import os, zipfile, zlib
     cache_dir = cache_dir or os.environ.get("LZANI_SYNTH_CACHE")
     if not cache_dir:
         base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
@@ -123,8 +123,8 @@ def make_set_cached(n, seed, cache_dir=None, **kw):
         off, codes = z["off"], z["codes"]
         if len(off) == n + 1 and int(z["crc"]) == zlib.crc32(codes.tobytes()):
             return [str(x) for x in z["names"]], [codes[off[i]:off[i + 1]] for i in range(n)]
-    except (OSError, KeyError, ValueError, EOFError):
-        pass                                   # no entry, or not one of ours: generate (and replace it)
+    except (OSError, KeyError, ValueError, EOFError, zipfile.BadZipFile, zlib.error):
+        pass                                   # no entry, a truncated / corrupt one, or not one of ours: generate (and replace it)
     names, seqs = make_set(n, seed, **kw)
     try:
         os.makedirs(cache_dir, mode=0o700, exist_ok=True)
