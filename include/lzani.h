@@ -137,9 +137,31 @@ typedef struct lzani_layout_info {
                                              * reference's presence filter in LDS (probe form, rows of >= 128 pairs) */
     int32_t  bitmap_launches;               /* pair-kernel launches of the last run fed by per-pair candidate bitmaps
                                              * (dense rows: presence matrix of the batch's references)                 */
-    int32_t  reserved_;
+    int32_t  rtc_launches;                  /* pair-kernel launches of the last run by a kernel compiled at run time for
+                                             * this context's parameters (lzani_get_rtc_info)                          */
 } lzani_layout_info;
 int lzani_get_layout(const lzani_ctx *ctx, lzani_layout_info *info);
+
+/* The reference reads its eight LZ parameters at run time and has one speed for all of them (lz-ani.cpp:205-260,
+ * parser.h:31).  Here the pair kernel folds them into its code: ahead of time for the defaults and for
+ * --mal 15 --msl 9 --reg 60, and for every other tuple (with mal, msl <= 15) by compiling the same kernel source
+ * with hipRTC the first time the context runs rows -- a few seconds once, then a code object cached on disk
+ * ($LZANI_RTC_CACHE, else $XDG_CACHE_HOME/lzani_rtc, else ~/.cache/lzani_rtc; LZANI_RTC=0 turns run-time compilation
+ * off).  If that fails the generic kernel runs; results are the same either way. */
+typedef struct lzani_rtc_info {
+    int32_t folded_ahead_of_time;   /* 1: the context's tuple is one of the two compiled ahead of time (nothing to build) */
+    int32_t null_chain;             /* 1: the tuple is inside what the hand-scheduled null chain is written for            */
+    int32_t kernels_built;          /* kernels of this context made ready at run time so far (compiled or loaded)          */
+    int32_t kernels_from_cache;     /* ... of which came from the disk cache                                               */
+    int32_t kernels_failed;         /* attempts that fell back to the generic kernel                                       */
+    int32_t reserved_;
+    double  build_ms;               /* host time spent building / loading them                                             */
+} lzani_rtc_info;
+int lzani_get_rtc_info(const lzani_ctx *ctx, lzani_rtc_info *info);
+/* Test hook (needs no GPU): compiles the pair kernel for a parameter tuple the way a context would (nfree: genomes
+ * without N; cand: 0 probe, 1 join, 2 candidate bitmaps) for the gfx target `arch` and returns the size of the code
+ * object, or a negative error code with the compiler's messages in `log`. */
+int64_t lzani_debug_rtc_compile(const lzani_params *p, int nfree, int cand, const char *arch, char *log, uint64_t log_cap);
 
 /* ---- Sharding over GPUs ---------------------------------------------------------------
  * The unit that shards is the reference's own work unit, one reference ROW (lz_matcher.cpp:196-255: a worker

@@ -34,9 +34,11 @@ int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_
 
 #include "lzani_core.h"
 #include "lzani_layout.h"
+#include "lzani_tables.h"
 #include "lzani_kernels_index.h"
 #include "lzani_kernels_cand.h"
 #include "lzani_kernels_pairs.h"
+#include "lzani_rtc.h"
 
 // ============================================================================================
 // Host side of the C-ABI
@@ -116,6 +118,11 @@ struct lzani_ctx {
     bool pm_attr_set = false;
 
     lzani_timing tm{};
+    // pair kernels compiled at run time for this context's parameters (lzani_rtc.h); none for the two ahead-of-time tuples
+    lzani_rtc::State rtc;
+    std::string arch;             // the device's gfx target, as hipRTC wants it
+    int rtc_launches = 0;         // pair-kernel launches of the last run by a run-time compiled kernel
+    u64 pairs_seen = 0;           // directed pairs this context has been asked for so far (a run-time compile must pay)
 
     void* comm = nullptr;         // ncclComm_t of lzani_comm_init (one process per GPU), lzani_multi.h
     u32 n_ranks = 1, rank = 0;
@@ -485,6 +492,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     c->batches_last_run = 0;
     c->blk_launches = 0;
     c->pm_launches = 0;
+    c->rtc_launches = 0;
     if (n_rows == 0) return LZANI_OK;
     const u64 n_pairs = row_off[n_rows];
     for (u32 k = 0; k < n_rows; ++k) {
@@ -714,6 +722,24 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         HIPCHK(c, d_cbits.alloc((size_t)max_blocks * 4 * cbits_stride));
     }
 
+    // Any other parameter tuple: the same kernel compiled for it the first time this context needs it (lzani_rtc.h) -- the
+    // eight ints folded into the code, the hand-written null chain included where the tuple is inside what the chain is
+    // written for (chain_params_ok).  Built (or loaded from the disk cache) here, ahead of the stream's first stamp.
+    // A compile takes 2-3 s and the folded kernel saves ~0.13 s per million pairs of 40 kbp: a code object that is not in
+    // the disk cache yet is built once the context has been asked for LZANI_RTC_MIN_PAIRS pairs in all (default 2 M: the
+    // first such run loses a second or two, every later run and every later process wins).
+    lzani_rtc::Kernel* rtc_k = nullptr;
+    c->pairs_seen += n_pairs;
+    if (!defp && !lgp && !rs && c->d_kmL && c->d_bk && lzani_rtc::enabled()) {
+        const int cand = pm ? 2 : (use_join && c->d_tw) ? 1 : c->d_tw ? 0 : -1;
+        const char* mp = getenv("LZANI_RTC_MIN_PAIRS");
+        const u64 min_pairs = mp ? strtoull(mp, nullptr, 10) : 2000000ull;
+        if (cand >= 0) {
+            rtc_k = lzani_rtc::get(c->rtc, c->P, c->all_nfree, cand, c->arch.c_str(), c->pairs_seen >= min_pairs);
+            if (!rtc_k && c->rtc.failed) TRACE("run-time compile unavailable (%s): the generic kernel runs", c->rtc.log.c_str());
+        }
+    }
+
     for (u32 b = 0; b < n_batches; ++b) {
         const u32 k0 = bstart[b], rows = bstart[b + 1] - k0;
         const u64 e0 = row_off[k0], e1 = row_off[k0 + rows];
@@ -796,6 +822,13 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 #define LZ_PAIRS_JOIN(N, D) hipLaunchKernelGGL((k_pairs<true, N, D, false, true, 1>), gd, bd, 0, c->stream, pa)
 #define LZ_PAIRS_PM(N, D) hipLaunchKernelGGL((k_pairs<true, N, D, false, true, 2>), gd, bd, 0, c->stream, pa)
             const bool fast = c->d_kmL != nullptr, tw = pa.tw != nullptr, nf = c->all_nfree;
+            auto rtc_launch = [&]() -> bool {
+                if (!rtc_k) return false;
+                void* kargs[] = {&pa};
+                if (hipModuleLaunchKernel(rtc_k->fn, gd.x, 1, 1, bd.x, 1, 1, 0, c->stream, kargs, nullptr) != hipSuccess) { (void)hipGetLastError(); return false; }
+                c->rtc_launches += 1;
+                return true;
+            };
             // Probe form, dense rows of hundreds of pairs: blocks of 16 waves with the reference's presence filter in LDS
             // (k_pairs_blk).  The rows a kmer-db filter leaves hold related pairs, where most positions pass the filter:
             // BASELINE configs[4] at full size is 6 % slower this way; LZANI_BLOCK_KERNEL=1/0 overrides.
@@ -821,14 +854,16 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             } else if (!fast) LZ_PAIRS(false, false, false, false, false);
             else if (pm) {                              // dense rows: candidate bitmaps made ahead (k_pm_cand)
                 c->pm_launches += 1;
-                if (nf && defp) LZ_PAIRS_PM(true, 1);
+                if (rtc_launch()) {}
+                else if (nf && defp) LZ_PAIRS_PM(true, 1);
                 else if (nf && lgp) LZ_PAIRS_PM(true, 2);
                 else if (nf) LZ_PAIRS_PM(true, 0);
                 else if (defp) LZ_PAIRS_PM(false, 1);
                 else if (lgp) LZ_PAIRS_PM(false, 2);
                 else LZ_PAIRS_PM(false, 0);
             } else if (tw && pa.skeys) {                // long genomes: candidates by the join
-                if (nf && defp) LZ_PAIRS_JOIN(true, 1);
+                if (rtc_launch()) {}
+                else if (nf && defp) LZ_PAIRS_JOIN(true, 1);
                 else if (nf && lgp) LZ_PAIRS_JOIN(true, 2);
                 else if (nf) LZ_PAIRS_JOIN(true, 0);
                 else if (defp) LZ_PAIRS_JOIN(false, 1);
@@ -846,7 +881,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (defp) hipLaunchKernelGGL((k_pairs_blk<false, true>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
                 else hipLaunchKernelGGL((k_pairs_blk<false, false>), gb, bb, lds, c->stream, pa, fw, (u32)c->blk_fold, c->d_blkctr);
             } else if (tw) {
-                if (nf && defp) LZ_PAIRS(true, true, true, false, true);
+                if (rtc_launch()) {}
+                else if (nf && defp) LZ_PAIRS(true, true, true, false, true);
                 else if (nf) LZ_PAIRS(true, true, false, false, true);
                 else if (defp) LZ_PAIRS(true, false, true, false, true);
                 else LZ_PAIRS(true, false, false, false, true);
@@ -911,6 +947,11 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
 #endif
     int trip = 0;
     HIPCHK(c, hipMemcpyFromSymbol(&trip, HIP_SYMBOL(g_guard_trip), sizeof(int)));
+    if (rtc_k && c->rtc_launches) {              // (a code object of its own has a loop guard of its own)
+        int t2 = 0, zero = 0;
+        HIPCHK(c, hipMemcpyDtoH(&t2, rtc_k->guard, sizeof(int)));
+        if (t2) { HIPCHK(c, hipMemcpyHtoD(rtc_k->guard, &zero, sizeof(int))); if (!trip) trip = t2; }
+    }
     if (trip) {
         int zero = 0;
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_guard_trip), &zero, sizeof(int)));
@@ -969,7 +1010,7 @@ int lzani_create(const lzani_params* p, int device_id, lzani_ctx** out)
     if (ok) {
         hipDeviceProp_t prop;
         ok = hipGetDeviceProperties(&prop, device_id) == hipSuccess;
-        if (ok) c->n_cus = prop.multiProcessorCount;
+        if (ok) { c->n_cus = prop.multiProcessorCount; c->arch = prop.gcnArchName; }
     }
     if (!ok) { lzani_destroy(c); return LZANI_ERR_DEVICE; }
     *out = c;
@@ -984,6 +1025,7 @@ void lzani_destroy(lzani_ctx* c)
     free_genomes(c);
     free_slabs(c);
     free_pm(c);
+    lzani_rtc::release(c->rtc);
     hipFree(c->d_cursor);
     hipFree(c->d_blkctr);
     for (auto& e : c->events) if (e) hipEventDestroy(e);
@@ -1166,8 +1208,34 @@ int lzani_get_layout(const lzani_ctx* c, lzani_layout_info* o)
     o->slots = c->slots; o->batches_last_run = c->batches_last_run;
     o->bytes_per_slot = 4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride);
     o->bytes_genomes = c->total_nm * (16 + 8) + (c->d_kmL ? c->total_nm * 64 * 8 : 0);
-    o->join_lists = c->join_mode; o->block_launches = c->blk_launches; o->bitmap_launches = c->pm_launches; o->reserved_ = 0;
+    o->join_lists = c->join_mode; o->block_launches = c->blk_launches; o->bitmap_launches = c->pm_launches; o->rtc_launches = c->rtc_launches;
     return LZANI_OK;
+}
+
+int lzani_get_rtc_info(const lzani_ctx* c, lzani_rtc_info* o)
+{
+    if (!c || !o) return LZANI_ERR_ARG;
+    const Params& q = c->P;
+    const bool aot = (q.mal == 11 && q.msl == 7 && q.mrd == 40 && q.mqd == 40 && q.reg == 35 && q.aw == 15 && q.am == 7 && q.ar == 3) ||
+                     (q.mal == 15 && q.msl == 9 && q.mrd == 40 && q.mqd == 40 && q.reg == 60 && q.aw == 15 && q.am == 7 && q.ar == 3);
+    o->folded_ahead_of_time = aot;
+    o->null_chain = chain_params_ok(q);
+    o->kernels_built = c->rtc.built; o->kernels_from_cache = c->rtc.from_cache; o->kernels_failed = c->rtc.failed;
+    o->reserved_ = 0;
+    o->build_ms = c->rtc.compile_ms;
+    return LZANI_OK;
+}
+
+int64_t lzani_debug_rtc_compile(const lzani_params* p, int nfree, int cand, const char* arch, char* log, uint64_t log_cap)
+{
+    if (!p || !arch || cand < 0 || cand > 2) return LZANI_ERR_ARG;
+    Params P{p->min_anchor_len, p->min_seed_len, p->max_dist_in_ref, p->max_dist_in_query,
+             p->min_region_len, p->approx_window, p->approx_mismatches, p->approx_run_len};
+    if (!params_supported(P) || P.mal > 15 || P.msl > 15) return LZANI_ERR_PARAMS;
+    std::string lg;
+    const size_t n = lzani_rtc::compile_only(P, nfree != 0, cand, arch, lg);
+    if (log && log_cap) { snprintf(log, (size_t)log_cap, "%s", lg.c_str()); }
+    return n ? (int64_t)n : (int64_t)LZANI_ERR_DEVICE;
 }
 
 int lzani_debug_get_index(lzani_ctx* c, uint32_t id, uint64_t* t2, uint64_t* nm, uint32_t* dirz,

@@ -31,9 +31,46 @@ __device__ __forceinline__ u64 wballot(bool b) { return __builtin_amdgcn_ballot_
 // a byte in all four bytes of a word: one byte permute (a 32-bit multiply by 0x01010101 runs at quarter rate)
 __device__ __forceinline__ u32 rep4(u32 b) { return __builtin_amdgcn_perm(b, b, 0u); }
 
+// The parameter sets a pair kernel folds into its code (template parameter DEFP of pair_body / k_pairs):
+//   0 = none (the eight ints are read from the kernel's arguments), 1 = the reference's defaults (params.h:34-48),
+//   2 = --mal 15 --msl 9 --reg 60 (BASELINE configs[3]), 9 = the set a run-time compile was made for (lzani_rtc.h: the
+//   eight ints arrive as the macros LZANI_P_*; the reference reads them at run time and has one speed for all of them,
+//   lz-ani.cpp:205-260 -- here every other tuple gets its own code object, built when a context first needs it).
+#if defined(LZANI_RTC)
+#define LZ_RTC_PARAMS Params{LZANI_P_MAL, LZANI_P_MSL, LZANI_P_MRD, LZANI_P_MQD, LZANI_P_REG, LZANI_P_AW, LZANI_P_AM, LZANI_P_AR}
+#else
+#define LZ_RTC_PARAMS Params{11, 7, 40, 40, 35, 15, 7, 3}
+#endif
+LZ_HD constexpr Params folded_params(int defp)
+{
+    return defp == 2 ? Params{15, 9, 40, 40, 60, 15, 7, 3} : defp == 9 ? LZ_RTC_PARAMS : Params{11, 7, 40, 40, 35, 15, 7, 3};
+}
+// What the hand-written null chain (DevWave::null_chain) takes for granted about the parameters: one lane per tracking
+// step (mqd + 1 <= 64), a seed window of 64 .. 128 positions (two loads of window k-mers, the spare lanes of the second
+// wrapping around to position 0), extensions that fit the null-extension record (aw <= 15, lzani_core.h), the window of
+// an extension step out of a 96-bit funnel (aw >= 2, ar <= aw), msl-mers that index the 16 Kbit seed bitmap directly
+// (msl <= 7) or through the hash bits k_kmers packs above them (msl 8, 9).
+LZ_HD constexpr bool chain_params_ok(const Params& p)
+{
+    return p.mal >= 1 && p.mal <= 15 && p.msl >= 1 && p.msl <= 9 && p.mqd >= 0 && p.mqd <= 63 && p.mrd >= 1 &&
+           p.mqd + p.mrd >= 64 && p.mqd + p.mrd <= 128 && p.aw >= 2 && p.aw <= 15 && p.ar <= p.aw && p.am >= 0 && p.reg >= 0 && p.reg < (1 << 20);
+}
+// CHAIN (template parameter of DevWave): 0 = no hand-written loop; 1 = the defaults, 3 = the defaults in a kernel for
+// genomes without N; 2 = the long-genome set; 9 / 10 = the run-time set (10: genomes without N)
+LZ_HD constexpr int chain_of(int defp, bool nfree)
+{
+    return defp == 1 ? (nfree ? 3 : 1) : defp == 2 ? 2 : defp == 9 ? (chain_params_ok(folded_params(9)) ? (nfree ? 10 : 9) : 0) : 0;
+}
+template <int CHAIN> struct ChainP {
+    static constexpr Params P = folded_params(CHAIN == 2 ? 2 : CHAIN >= 9 ? 9 : 1);
+    static constexpr bool NF = CHAIN == 3 || CHAIN == 10;
+    enum { MAL = P.mal, MSL = P.msl, MRD = P.mrd, MQD = P.mqd, REG = P.reg, AW = P.aw, AM = P.am > 16 ? 16 : P.am, AR = P.ar < 1 ? 1 : P.ar,
+           NT = MQD + 1, WIN = MQD + MRD };
+};
+
 template <bool FAST, bool BK = false, bool JOIN = false, int CHAIN = 0, bool LFLT = false>
 struct DevWave {
-    static constexpr bool NULL_CHAIN = CHAIN != 0;      // (1 = the default parameters, 3 = the same in a kernel for genomes without N, 2 = mal 15, msl 9, reg 60: see pair_body)
+    static constexpr bool NULL_CHAIN = CHAIN != 0;      // (see ChainP)
     const Params& P;
     TextView R, Q;
     IndexView I;
@@ -663,10 +700,11 @@ struct DevWave {
     // dropped.)  Only "no seed candidate in j's tracking round" is left to the loop.  The parameters are the defaults.
     __device__ __forceinline__ void chain_classes()
     {
-        enum { MQD = 40, MRD = 40, MSL = CHAIN == 2 ? 9 : 7, REG = CHAIN == 2 ? 60 : 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };
+        typedef ChainP<CHAIN> CP;
+        enum { MQD = CP::MQD, MRD = CP::MRD, MSL = CP::MSL, REG = CP::REG, AW = CP::AW, NT = CP::NT, WIN = CP::WIN };
         // (N-free pair: the rounds of the fast turns -- the ones a GO bit lets through -- only ever see real msl-mers: all 64
         // query lanes, all 80 window positions inside one strand; their address arithmetic then needs no clamp, LZ_NC_WORD7N)
-        constexpr bool nf = CHAIN == 3;             // (the default parameters in a kernel for genomes without N)
+        constexpr bool nf = CP::NF;                 // (a kernel for genomes without N)
         const int ilim = imin(imin(scan_pos, iend) - NT, nf ? Q.L - MSL + 1 - 64 : iend), rlim = R.len - MSL + 1 - WIN;
         const int len = a_len;
         const bool plain = len > 0;
@@ -807,7 +845,9 @@ struct DevWave {
                                               int& add_tm, int& add_tl, int& add_tc)
     {
         static_assert(!CHAIN || (FAST && BK), "the null chain reads the anchor queue");
-        enum { MQD = 40, MRD = 40, MSL = CHAIN == 2 ? 9 : 7, REG = CHAIN == 2 ? 60 : 35, AW = 15, NT = MQD + 1, WIN = NT - 1 + MRD };    // params.h:34-48 (CHAIN == 2: --msl 9 --reg 60)
+        typedef ChainP<CHAIN> CP;                              // params.h:34-48, or the set this kernel was compiled for
+        enum { MQD = CP::MQD, MRD = CP::MRD, MSL = CP::MSL, REG = CP::REG, AW = CP::AW, AM = CP::AM, AR = CP::AR, NT = CP::NT, WIN = CP::WIN };
+        static_assert(!CHAIN || chain_params_ok(CP::P), "the null chain is not written for these parameters");
         const int ilim = imin(scan_pos, iend) - NT;             // the queue and the query cover the tracking steps of i <= ilim
         const int rlim = R.len - MSL + 1 - WIN;                 // the seed window of r_end <= rlim is complete
         const u32 ldsb = (u32)(size_t)bitmap;                   // LDS byte offset (low half of the flat address)
@@ -870,6 +910,11 @@ struct DevWave {
 #define LZ_NC_WORD9(A, T, K) \
             "v_lshrrev_b32_e32 %[" A "], 23, %[" K "]\n\t" \
             "v_lshrrev_b32_e32 %[" T "], 18, %[" K "]\n\t" \
+            "v_lshlrev_b32_e32 %[" T "], %[" T "], %[one]\n\t" \
+            "v_lshl_add_u32 %[" A "], %[" A "], 2, %[ldsb]\n\t"
+#define LZ_NC_WORD8(A, T, K)                /* (msl 8: the hash sits at bit 16, and KM_INVALID must stay inside the bitmap) */ \
+            "v_bfe_u32 %[" A "], %[" K "], %[KS5], 9\n\t" \
+            "v_lshrrev_b32_e32 %[" T "], %[KS], %[" K "]\n\t" \
             "v_lshlrev_b32_e32 %[" T "], %[" T "], %[one]\n\t" \
             "v_lshl_add_u32 %[" A "], %[" A "], 2, %[ldsb]\n\t"
 #define LZ_NC_ROUND_X(WORD, WAIT, QK, K0, K1) \
@@ -1201,9 +1246,9 @@ struct DevWave {
             "s_add_i32 %[rec], %[rend], %[t2]\n\t"          /* the seed in the reference ... */ \
             "s_add_i32 %[cls], %[i], %[t0]\n\t"             /* ... and in the query */ \
             /* bounds: query [cls + 7, cls + 71) inside [0, Lq), Lq = qend - 33 (qend = the scan's end D - msl = Lq + mrd - msl; a pair */ \
-            /* with an N in it has qend far below zero); reference the same inside [0, L) or [rc0, rc0 + L), L = (rlim - 34) / 2 */ \
+            /* with an N in it has qend far below zero); reference the same inside [0, L) or [rc0, rc0 + L), L = (rlim - C41M) / 2 */ \
             /* (rlim = 2 L + 3 mrd - msl + 1 - 80), rc0 = L + 2 mrd */ \
-            "s_sub_i32 %[t1], %[qend], 104\n\t" \
+            "s_sub_i32 %[t1], %[qend], %[CQ64]\n\t" \
             LZ_NC_WHY(3) \
             "s_cmp_gt_i32 %[cls], %[t1]\n\t" \
             "s_cbranch_scc1 Lnc_end_%=\n\t" \
@@ -1212,7 +1257,7 @@ struct DevWave {
             "s_add_i32 %[t2], %[rec], %[MSL64]\n\t" \
             "s_cmp_le_i32 %[t2], %[t1]\n\t" \
             "s_cbranch_scc1 Lnc_sok_%=\n\t" \
-            "s_add_i32 %[kb], %[t1], 80\n\t"                /* rc0 */ \
+            "s_add_i32 %[kb], %[t1], %[C2MRD]\n\t"                /* rc0 */ \
             "s_cmp_lt_i32 %[rec], %[kb]\n\t" \
             "s_cbranch_scc1 Lnc_end_%=\n\t"                 /* runs from the forward strand into the pad */ \
             "s_add_i32 %[kb], %[kb], %[t1]\n\t" \
@@ -1266,7 +1311,7 @@ struct DevWave {
             "s_lshr_b32 %[kb], %[kb], 1\n\t"                /* L */ \
             "s_cmp_le_i32 %[t2], %[kb]\n\t" \
             "s_cbranch_scc1 Lnc_hull_%=\n\t" \
-            "s_add_i32 %[kc], %[kb], 80\n\t"                /* rc0 */ \
+            "s_add_i32 %[kc], %[kb], %[C2MRD]\n\t"                /* rc0 */ \
             "s_cmp_lt_i32 %[rend], %[kc]\n\t" \
             "s_cbranch_scc1 Lnc_end_%=\n\t" \
             "s_add_i32 %[kc], %[kc], %[kb]\n\t" \
@@ -1379,11 +1424,11 @@ struct DevWave {
             /* if the 15 symbols ending at it hold more than 7 mismatches, and qualifies if it and the two before it match. */ \
             /* The window of lane j = bits [j, j + 15) of Bf << 14, as three words e0 (gap), e1 (kc), e2 (kb) */ \
             "s_mov_b64 vcc, %[seed]\n\t" \
-            "s_lshl_b32 %[gap], vcc_lo, 14\n\t" \
-            "s_lshr_b32 %[kb], vcc_lo, 18\n\t" \
-            "s_lshl_b32 %[kc], vcc_hi, 14\n\t" \
+            "s_lshl_b32 %[gap], vcc_lo, %[AW1]\n\t" \
+            "s_lshr_b32 %[kb], vcc_lo, %[AW1C]\n\t" \
+            "s_lshl_b32 %[kc], vcc_hi, %[AW1]\n\t" \
             "s_or_b32 %[kc], %[kc], %[kb]\n\t" \
-            "s_lshr_b32 %[kb], vcc_hi, 18\n\t" \
+            "s_lshr_b32 %[kb], vcc_hi, %[AW1C]\n\t" \
             "v_mov_b32_e32 %[rk0], %[gap]\n\t" \
             "v_mov_b32_e32 %[rk1], %[kc]\n\t" \
             "v_mov_b32_e32 %[qk], %[kb]\n\t" \
@@ -1391,10 +1436,10 @@ struct DevWave {
             "v_alignbit_b32 %[a0], %[rk1], %[rk0], %[lane]\n\t" \
             "v_alignbit_b32 %[a1], %[qk], %[rk1], %[lane]\n\t" \
             "v_cndmask_b32_e32 %[a0], %[a1], %[a0], vcc\n\t" \
-            "v_and_b32_e32 %[a0], 0x7fff, %[a0]\n\t" \
+            "v_and_b32_e32 %[a0], %[AWM], %[a0]\n\t" \
             "v_bcnt_u32_b32 %[a1], %[a0], 0\n\t" \
-            "v_and_b32_e32 %[a0], 0x7000, %[a0]\n\t" \
-            "v_cmp_lt_u32_e32 vcc, 7, %[a1]\n\t"            /* brk */ \
+            "v_and_b32_e32 %[a0], %[ARM], %[a0]\n\t" \
+            "v_cmp_lt_u32_e32 vcc, %[AM], %[a1]\n\t"            /* brk */ \
             "v_cmp_eq_u32_e64 %[m], 0, %[a0]\n\t"           /* qual */ \
             "s_nop 0\n\t" \
             "s_cmp_eq_u64 vcc, 0\n\t" \
@@ -1478,13 +1523,15 @@ struct DevWave {
               [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS), \
               [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), \
               [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one), \
-              [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64), [MSL] "n"(MSL), [MSL64] "n"(MSL + 64), [C41M] "n"(41 - MSL), [C40M] "n"(40 - MSL) \
+              [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64), [MSL] "n"(MSL), [MSL64] "n"(MSL + 64), [C41M] "n"(3 * MRD + 1 - WIN - MSL), [C40M] "n"(MRD - MSL), [CQ64] "n"(MRD + 64), [C2MRD] "n"(2 * MRD), \
+              [AW1] "n"(AW - 1), [AW1C] "n"(33 - AW), [AWM] "n"((1 << AW) - 1), [ARM] "n"(((1 << AR) - 1) << (AW - AR)), [AM] "n"(AM), [KS5] "n"(2 * MSL + 5), [KS] "n"(2 * MSL) \
             : "vcc", "scc", "memory");
 #ifdef LZANI_PHASE_TIME
         const unsigned long long pt_t0 = pt_now();
 #endif
-        if constexpr (CHAIN == 2) { LZ_NC_ASM(LZ_NC_WORD9, LZ_NC_WORD9) }
-        else if constexpr (CHAIN == 3) { LZ_NC_ASM(LZ_NC_WORD7, LZ_NC_WORD7N) }      // (N-free by instantiation: see chain_classes)
+        if constexpr (MSL == 9) { LZ_NC_ASM(LZ_NC_WORD9, LZ_NC_WORD9) }
+        else if constexpr (MSL == 8) { LZ_NC_ASM(LZ_NC_WORD8, LZ_NC_WORD8) }
+        else if constexpr (CP::NF) { LZ_NC_ASM(LZ_NC_WORD7, LZ_NC_WORD7N) }          // (N-free by instantiation: see chain_classes)
         else { LZ_NC_ASM(LZ_NC_WORD7, LZ_NC_WORD7) }
 #ifdef LZANI_PHASE_TIME
         pt_chain += pt_now() - pt_t0;
@@ -1497,6 +1544,7 @@ struct DevWave {
 #undef LZ_NC_WORD7
 #undef LZ_NC_WORD7N
 #undef LZ_NC_WORD9
+#undef LZ_NC_WORD8
 #undef LZ_NC_FTURN
 #undef LZ_NC_FIX
 #undef LZ_NC_SEEDS
@@ -1833,7 +1881,7 @@ template <bool FAST, bool NFREE, int DEFP, bool ALN, bool BK, int CAND, bool LFL
 __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int lane, u32* lds, const u32* flt)
 {
     constexpr bool JOIN = CAND != 0;
-    const Params Pk = DEFP == 1 ? Params{11, 7, 40, 40, 35, 15, 7, 3} : DEFP == 2 ? Params{15, 9, 40, 40, 60, 15, 7, 3} : a.P;
+    const Params Pk = DEFP ? folded_params(DEFP) : a.P;
     const u32 slot = a.qorder[lo];
     const u32 r = a.ref_ids[slot];
     const u64 e = a.row_off[slot] + j;
@@ -1844,7 +1892,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     if (CAND == 1) {
         cand_bits = a.cbits + (u64)(blockIdx.x * 4 + (threadIdx.x >> 6)) * a.cbits_stride;
         join_candidates(a.tw + slot * a.tw_stride, a.geo.kb, a.geo.dirbits, a.geo.posbits, a.geo.tagmask,
-                        a.skeys + a.soff[q], a.scnt[q], cand_bits, ((a.G.L[q] + (DEFP ? 40 : a.P.mrd)) >> 6) + 8, lane);
+                        a.skeys + a.soff[q], a.scnt[q], cand_bits, ((a.G.L[q] + Pk.mrd) >> 6) + 8, lane);
     }
     const int Lr = a.G.L[r], Lq = a.G.L[q];
     const u64 ro = a.G.nmoff[r], qo = a.G.nmoff[q];
@@ -1857,9 +1905,9 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
     const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
 #ifdef LZANI_STAMPS
-    constexpr int CHAIN = (FAST && BK && !ALN && !LFLT) ? (DEFP == 1 && NFREE ? 3 : DEFP) : 0;     // (diagnostic build: the block kernel's stamps do not stay scalar around the hand-written loop)
+    constexpr int CHAIN = (FAST && BK && !ALN && !LFLT) ? chain_of(DEFP, NFREE) : 0;     // (diagnostic build: the block kernel's stamps do not stay scalar around the hand-written loop)
 #else
-    constexpr int CHAIN = (FAST && BK && !ALN) ? (DEFP == 1 && NFREE ? 3 : DEFP) : 0;
+    constexpr int CHAIN = (FAST && BK && !ALN) ? chain_of(DEFP, NFREE) : 0;
 #endif
     DevWave<FAST, BK, JOIN, CHAIN, LFLT> w{Pk, ref_view(a.G.t2 + 2 * ro, a.G.nm + ro, Lr, Pk.mrd, nfree),
                     qry_view(a.G.t2 + 2 * qo, a.G.nm + qo, Lq, Pk.mrd, nfree), iv, lane,
@@ -1936,8 +1984,8 @@ __device__ __forceinline__ u32 row_of_ticket(const u64* __restrict__ qcum, u32 r
 #ifndef LZANI_WAVES_PER_SIMD
 #define LZANI_WAVES_PER_SIMD 8                 // (occupancy experiments: the register budget of the pair kernel)
 #endif
-template <bool FAST, bool NFREE, int DEFP, bool ALN = false, bool BK = false, int CAND = 0>
-__global__ void __launch_bounds__(256, LZANI_WAVES_PER_SIMD) k_pairs(PairArgs a)
+template <bool FAST, bool NFREE, int DEFP, bool ALN, bool BK, int CAND>
+__device__ __forceinline__ void pairs_loop(const PairArgs& a)
 {
     const int lane = threadIdx.x & 63;
     __shared__ u32 s_seed[4][SEED_LDS_WORDS];
@@ -1963,6 +2011,11 @@ __global__ void __launch_bounds__(256, LZANI_WAVES_PER_SIMD) k_pairs(PairArgs a)
         const u32 lo = row_of_ticket(a.qcum, rb, re, tk);
         pair_body<FAST, NFREE, DEFP, ALN, BK, CAND, false>(a, lo, (u32)(tk - a.qcum[lo]), lane, lds, nullptr);
     }
+}
+template <bool FAST, bool NFREE, int DEFP, bool ALN = false, bool BK = false, int CAND = 0>
+__global__ void __launch_bounds__(256, LZANI_WAVES_PER_SIMD) k_pairs(PairArgs a)
+{
+    pairs_loop<FAST, NFREE, DEFP, ALN, BK, CAND>(a);
 }
 
 // The same pairs by BLOCKS of 16 waves that stay on one reference at a time (probe form with tag words, rows of
@@ -2044,3 +2097,12 @@ __global__ void __launch_bounds__(64 * BLK_WAVES, 8) k_pairs_blk(PairArgs a, u32
 }
 
 }  // namespace lzani
+
+// Run-time compiled instantiation (lzani_rtc.h): this header as text behind the macros LZANI_P_* (the eight LZ parameters
+// of the context), LZANI_RTC_NFREE and LZANI_RTC_CAND; one kernel per code object, found by its C name.
+#if defined(LZANI_RTC)
+extern "C" __global__ void __launch_bounds__(256, LZANI_WAVES_PER_SIMD) lzani_rtc_pairs(lzani::PairArgs a)
+{
+    lzani::pairs_loop<true, (LZANI_RTC_NFREE) != 0, 9, false, true, LZANI_RTC_CAND>(a);
+}
+#endif

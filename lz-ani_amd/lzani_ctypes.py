@@ -30,7 +30,7 @@ EXPORTS = ("lzani_default_params", "lzani_create", "lzani_destroy", "lzani_last_
            "lzani_debug_get_index", "lzani_run_rows_regions", "lzani_get_layout",
            "lzani_row_costs", "lzani_partition_rows", "lzani_comm_unique_id", "lzani_comm_init", "lzani_comm_allgather",
            "lzani_comm_gatherv", "lzani_group_create", "lzani_group_destroy", "lzani_group_last_error",
-           "lzani_group_set_genomes", "lzani_group_run_rows", "lzani_group_get_timing", "lzani_plan_gather")
+           "lzani_group_set_genomes", "lzani_group_run_rows", "lzani_group_get_timing", "lzani_plan_gather", "lzani_get_rtc_info", "lzani_debug_rtc_compile")
 
 
 class LzaniError(RuntimeError):
@@ -48,17 +48,23 @@ class LayoutInfo(C.Structure):
                 ("kmer_words", C.c_int32), ("bucket_table", C.c_int32), ("tag_words", C.c_int32), ("n_free", C.c_int32),
                 ("slots", C.c_uint32), ("batches_last_run", C.c_uint32), ("bytes_per_slot", C.c_uint64),
                 ("bytes_genomes", C.c_uint64), ("join_lists", C.c_int32), ("block_launches", C.c_int32),
-                ("bitmap_launches", C.c_int32), ("reserved_", C.c_int32)]
+                ("bitmap_launches", C.c_int32), ("rtc_launches", C.c_int32)]
+
+
+class RtcInfo(C.Structure):
+    _fields_ = [("folded_ahead_of_time", C.c_int32), ("null_chain", C.c_int32), ("kernels_built", C.c_int32),
+                ("kernels_from_cache", C.c_int32), ("kernels_failed", C.c_int32), ("reserved_", C.c_int32), ("build_ms", C.c_double)]
 
 
 def build_library(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     deps = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("lzani_core.h", "lzani_layout.h", "lzani_kernels_index.h",
-                                                             "lzani_kernels_cand.h", "lzani_kernels_pairs.h", "lzani_multi.h", "lzani_sort.hip")] + [os.path.join(ROOT, "include", "lzani.h")]
+                                                             "lzani_kernels_cand.h", "lzani_kernels_pairs.h", "lzani_multi.h", "lzani_sort.hip", "lzani_tables.h", "lzani_rtc.h")] + [os.path.join(ROOT, "include", "lzani.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wno-unused-value", "-o", LIB_PATH, SRC, os.path.join(HERE, "csrc", "lzani_sort.hip"), "-lrccl"]
+           "-Wno-unused-value", "-I" + os.path.join(HERE, "csrc"), "-I" + os.path.join(ROOT, "include"),      # (-I: the .incbin of lzani_rtc.h)
+           "-o", LIB_PATH, SRC, os.path.join(HERE, "csrc", "lzani_sort.hip"), "-lrccl", "-lhiprtc"]
     subprocess.check_call(cmd)
     return LIB_PATH
 
@@ -83,6 +89,9 @@ def load_library():
         lib.lzani_run_rows_device.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.lzani_get_timing.argtypes = [C.c_void_p, C.c_void_p]
         lib.lzani_get_layout.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lzani_get_rtc_info.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lzani_debug_rtc_compile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64]
+        lib.lzani_debug_rtc_compile.restype = C.c_int64
         lib.lzani_run_rows_regions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lzani_debug_get_index.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
@@ -162,6 +171,15 @@ def partition_rows(n_rows, n_parts, row_cost=None):
     if rc != 0:
         raise LzaniError(f"lzani_partition_rows: {ERRORS.get(rc, rc)}")
     return part
+
+
+def rtc_compile(params=None, nfree=True, cand=2, arch="gfx950"):
+    """Compile-only check of the run-time compiled pair kernel (no GPU needed): (code object bytes or negative code, log)."""
+    lib = load_library()
+    arr, _ = params_array(params)
+    log = C.create_string_buffer(1 << 16)
+    n = lib.lzani_debug_rtc_compile(arr, int(bool(nfree)), int(cand), arch.encode(), log, len(log))
+    return int(n), log.value.decode(errors="replace")
 
 
 def comm_unique_id():
@@ -332,6 +350,11 @@ class Engine:
         o = LayoutInfo()
         self._check(self.lib.lzani_get_layout(self.h, C.byref(o)), "lzani_get_layout")
         return {k: getattr(o, k) for k, _ in LayoutInfo._fields_}
+
+    def rtc_info(self):
+        o = RtcInfo()
+        self._check(self.lib.lzani_get_rtc_info(self.h, C.byref(o)), "lzani_get_rtc_info")
+        return {k: getattr(o, k) for k, _ in RtcInfo._fields_ if k != "reserved_"}
 
     def debug_index(self, gid):
         mrd = self.params["mrd"]

@@ -48,3 +48,16 @@ def test_python_binding_has_no_cpu_fallback(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "_lib", None)
     with pytest.raises(L.LzaniError):
         L.load_library()
+
+
+def test_run_time_compile_of_the_pair_kernel_without_a_gpu():
+    """The pair kernel as hipRTC compiles it for a context's own parameter tuple (lzani_rtc.h): the embedded headers
+    assemble into a translation unit that compiles for gfx950 -- inside the null chain's envelope (its constants become
+    immediates of the hand-written loop: every one must be encodable), with msl 8, and outside the envelope."""
+    import lzani_ctypes as L
+    for prm, nfree, cand in ((dict(reg=36), True, 2), (dict(mal=12, msl=8, mrd=50, mqd=30, reg=200, aw=12, am=5, ar=2), False, 0),
+                             (dict(aw=20), True, 1)):
+        n, log = L.rtc_compile(prm, nfree=nfree, cand=cand)
+        assert n > 20000, (prm, n, log[:2000])
+    n, _ = L.rtc_compile(dict(mal=20))
+    assert n == -2                      # LZANI_ERR_PARAMS: no k-mer words beyond 15, nothing to compile

@@ -749,6 +749,63 @@ def test_presence_matrix_after_sparse_run_and_allocation_fallback(monkeypatch):
     eng.close()
 
 
+def test_run_time_compiled_parameter_tuples(monkeypatch, tmp_path):
+    """Every parameter tuple other than the two compiled ahead of time gets the pair kernel compiled FOR it when the context
+    first needs it (lzani_rtc.h: the eight ints folded in, the hand-written null chain included where the tuple is inside
+    its envelope): tuples inside and outside the envelope, msl 8 (its own seed-bitmap mapping), dense rows (candidate
+    bitmaps) and filtered rows (probes), genomes with and without N -- every launch a run-time compiled one, results
+    equal to the oracle's; the second context finds the code objects in the disk cache."""
+    monkeypatch.setenv("LZANI_RTC_MIN_PAIRS", "0")
+    monkeypatch.setenv("LZANI_RTC_CACHE", str(tmp_path))
+    monkeypatch.setenv("LZANI_PM_MIN_ROWS", "1")
+    _, seqs = SG.make_set(30, 53, lmin=17000, lmax=21000, fam=6)
+    withn = [s.copy() for s in seqs[:18]]
+    for k in range(0, 18, 4):
+        withn[k][500:500 + 7 + 3 * k] = 5
+    tuples = (dict(reg=36), dict(am=6), dict(mal=12, msl=8, mrd=50, mqd=30, reg=40, aw=12, am=5, ar=2),
+              dict(mal=9, msl=5, mrd=64, mqd=60, aw=2, am=0, ar=1), dict(aw=20, reg=50))
+    for prm, chain in zip(tuples, (1, 1, 1, 1, 0)):
+        for name, data in (("N-free", seqs), ("with N", withn)):
+            n = len(data)
+            want = O.oracle_all2all(data, prm, threads=16)
+            eng = L.Engine(prm)
+            eng.set_genomes(data)
+            got = eng.all2all()
+            lay = eng.layout()
+            assert lay["bitmap_launches"] == 1 and lay["rtc_launches"] == 1, (prm, name, lay, eng.rtc_info())
+            bad = np.argwhere((got != want).any(axis=2))
+            assert len(bad) == 0, (prm, name, "dense", bad[:3].tolist())
+            rr = np.arange(n, dtype=np.uint32)
+            off = np.arange(n + 1, dtype=np.uint64) * np.uint64(3)
+            q = np.array([[(r + 1) % n, (r + 2) % n, (r + 7) % n] for r in range(n)], dtype=np.uint32).reshape(-1)
+            out = eng.run_rows(rr, off, q).reshape(n, 3, 3)
+            lay = eng.layout()
+            assert lay["bitmap_launches"] == 0 and lay["rtc_launches"] == 1, (prm, name, lay)
+            for r in range(n):
+                assert np.array_equal(out[r], want[r, [(r + 1) % n, (r + 2) % n, (r + 7) % n]]), (prm, name, "rows", r)
+            info = eng.rtc_info()
+            eng.close()
+            assert info["folded_ahead_of_time"] == 0 and info["null_chain"] == chain and info["kernels_built"] == 2 and info["kernels_failed"] == 0, info
+    # the same tuple again: from the disk cache
+    eng = L.Engine(tuples[0])
+    eng.set_genomes(seqs)
+    eng.all2all()
+    info = eng.rtc_info()
+    eng.close()
+    assert info["kernels_built"] == 1 and info["kernels_from_cache"] == 1, info
+    # below the threshold nothing is compiled, and LZANI_RTC=0 turns it off
+    monkeypatch.setenv("LZANI_RTC_MIN_PAIRS", "100000000")
+    eng = L.Engine(dict(reg=37))
+    eng.set_genomes(seqs[:8])
+    got = eng.all2all()
+    assert eng.layout()["rtc_launches"] == 0 and eng.rtc_info()["kernels_built"] == 0
+    eng.close()
+    assert np.array_equal(got, O.oracle_all2all(seqs[:8], dict(reg=37), threads=16))
+    eng = L.Engine()
+    assert eng.rtc_info()["folded_ahead_of_time"] == 1
+    eng.close()
+
+
 def test_presence_matrix_with_query_lists():
     """Candidate bitmaps for rows with query LISTS that are dense where they are: the row x column blocks a host cuts
     a dense all2all into so that it can emit finished rows while the GPU works on the next block (lz-ani does) --

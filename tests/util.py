@@ -217,6 +217,41 @@ def fuzz_case_medium(st):
     return prm, seqs
 
 
+def fuzz_params_chain(st):
+    """A random parameter tuple INSIDE what the hand-written null chain is written for (chain_params_ok in
+    lzani_kernels_pairs.h: mqd <= 63, 64 <= mqd + mrd <= 128, 2 <= aw <= 15, ar <= aw, msl <= 9) and inside the reference's
+    own well-defined range (mqd <= mrd); never one of the two tuples compiled ahead of time."""
+    while True:
+        mrd = st.randint(32, 64)
+        mqd = st.randint(64 - mrd, min(mrd, 63))
+        msl = st.randint(4, 9)
+        aw = st.randint(2, 15)
+        prm = dict(mal=st.randint(max(msl, 9), 13), msl=msl, mrd=mrd, mqd=mqd, reg=st.randint(10, 80), aw=aw,
+                   am=st.randint(0, aw), ar=st.randint(0, min(aw, 6)))
+        if prm != DEFAULTS and prm != dict(DEFAULTS, **VARIANTS["long"]):
+            return prm
+
+
+def fuzz_seqs_medium(st, with_n=None):
+    """The sequences of fuzz_case_medium (an ancestor, two mutated copies, a stranger; 8-70 kbp); with_n: False = no N
+    anywhere (the N-free kernel instantiation), True = N runs in one copy, None = either."""
+    L = st.randint(8000, 70000)
+    base = (st.u64(L) % np.uint64(4)).astype(np.uint8)
+    seqs = [base, SG.mutate(base, 0.01 + 0.12 * st.one(), st)]
+    g = SG.mutate(base, 0.02 + 0.2 * st.one(), st).copy()
+    n_runs = st.one() < 0.5 if with_n is None else with_n
+    if n_runs:
+        for _ in range(st.randint(1, 3)):
+            a = st.randint(0, len(g) - 200)
+            g[a:a + st.randint(1, 120)] = 5
+    else:
+        a = st.randint(0, len(g) - 3000)
+        g[a:a + 2500] = (3 - g[a:a + 2500][::-1])
+    seqs.append(np.ascontiguousarray(g))
+    seqs.append((st.u64(st.randint(8000, 70000)) % np.uint64(4)).astype(np.uint8))
+    return seqs
+
+
 def fuzz_case_large(st):
     """Like fuzz_case_medium at 0.3-1.2 Mbp: directories of 2^20 buckets and more (the sort-based index build) and, from
     ~0.5 Mbp on, tag words of 8 MB (candidates by the join): an ancestor, a mutated copy, a stranger."""

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Long differential fuzz of the HIP path against the oracle.  Usage: tools/fuzz_gpu.py [seed] [seconds] [medium|large]
 `medium`: 8-70 kbp genomes (tag words, bucket table, LDS index build in use) instead of the tiny ones;
-`large`: 0.3-1.2 Mbp (sort-based index build, join form of candidate detection)."""
+`large`: 0.3-1.2 Mbp (sort-based index build, join form of candidate detection);
+`rtc [cases_per_tuple]`: random parameter TUPLES through the pair kernels compiled at run time for them (lzani_rtc.h) --
+three tuples out of four inside the null chain's envelope -- cases_per_tuple (default 50) sequence sets of 8-70 kbp each, with
+and without N, dense rows by candidate bitmaps and filtered rows by probes; every launch must be a run-time compiled one."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("lz-ani_amd", "oracle", "tools", "tests"):
@@ -11,6 +14,48 @@ import lzani_ctypes as L
 import oracle as O
 import synth_genomes as SG
 import util as U
+
+if len(sys.argv) > 3 and sys.argv[3] == "rtc":
+    os.environ["LZANI_RTC_MIN_PAIRS"] = "0"
+    st = SG.Stream(int(sys.argv[1]))
+    budget = float(sys.argv[2])
+    per = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+    t0, tuples, cases, bad, launches, chain_tuples, build_ms = time.time(), 0, 0, 0, 0, 0, 0.0
+    while time.time() - t0 < budget:
+        prm = U.fuzz_params_chain(st) if st.one() < 0.75 else U.fuzz_case_medium(st)[0]
+        if prm == U.DEFAULTS or prm == dict(U.DEFAULTS, **U.VARIANTS["long"]):
+            continue
+        tuples += 1
+        for k in range(per):
+            seqs = U.fuzz_seqs_medium(st, with_n=(k % 3 == 2))
+            want = O.oracle_all2all(seqs, prm, threads=16)
+            eng = L.Engine(prm)
+            eng.set_genomes(seqs)
+            os.environ["LZANI_PM_MIN_ROWS"] = "1"
+            got = eng.all2all()                                   # dense rows: candidate bitmaps
+            del os.environ["LZANI_PM_MIN_ROWS"]
+            la = eng.layout()
+            n = len(seqs)
+            ref_ids = np.arange(n, dtype=np.uint32)
+            qs = [[x for x in range(n) if x != r] for r in range(n)]
+            row_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(n - 1)
+            out = eng.run_rows(ref_ids, row_off, np.array(qs, np.uint32).reshape(-1)).reshape(n, n - 1, 3)   # query lists: probes
+            lb = eng.layout()
+            info = eng.rtc_info()
+            eng.close()
+            launches += la["rtc_launches"] + lb["rtc_launches"]
+            if k == 0:
+                chain_tuples += info["null_chain"]
+            build_ms += info["build_ms"]
+            ok = np.array_equal(got, want) and all(np.array_equal(out[r], want[r, qs[r]]) for r in range(n))
+            if not ok or la["rtc_launches"] != la["bitmap_launches"] or la["bitmap_launches"] != 1 or lb["rtc_launches"] != 1:
+                bad += 1
+                print("RTC MISMATCH" if not ok else "NOT THE RUN-TIME KERNEL", prm, [len(x) for x in seqs], la, lb, info, flush=True)
+            cases += 1
+        print("... tuple", tuples, prm, "cases", cases, "bad", bad, "%.0f s" % (time.time() - t0), flush=True)
+    print("rtc fuzz: tuples", tuples, "(inside the chain's envelope:", chain_tuples, ") cases", cases, "mismatches", bad,
+          "run-time compiled launches", launches, "build+load ms in all %.0f" % build_ms)
+    sys.exit(1 if bad else 0)
 
 st = SG.Stream(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60
