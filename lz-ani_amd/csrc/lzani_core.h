@@ -644,6 +644,16 @@ template <class W> struct wave_has_null_chain<W, std::void_t<decltype(W::NULL_CH
 template <class W, class = void> struct wave_has_mism3 : std::false_type {};
 template <class W> struct wave_has_mism3<W, std::void_t<decltype(W::HAS_MISM3)>> : std::bool_constant<W::HAS_MISM3> {};
 
+// a policy may find the event behind a match in a related stretch straight from the packed texts, with the masks of the close
+// match's gap fill and first forward chunk in hand (DevWave::stretch_event)
+template <class W, class = void> struct wave_has_stretch : std::false_type {};
+template <class W> struct wave_has_stretch<W, std::void_t<decltype(W::HAS_STRETCH)>> : std::bool_constant<W::HAS_STRETCH> {};
+template <class W, class = void> struct wave_has_stretch_chain : std::false_type {};
+template <class W> struct wave_has_stretch_chain<W, std::void_t<decltype(W::HAS_STRETCH_CHAIN)>> : std::bool_constant<W::HAS_STRETCH_CHAIN> {};
+struct NoStretch { bool masks; u64 Lm, Rm, Bf; int to_scan, nf; };
+template <class W, bool HAS> struct stretch_type { typedef NoStretch type; };
+template <class W> struct stretch_type<W, true> { typedef typename W::Stretch type; };
+
 template <class W, bool ALN = false>
 struct PairMachine {
     W& w;
@@ -695,11 +705,24 @@ struct PairMachine {
     {
         int maxlen = imin(D - q0, T - r0);
         int last = 0, last_mm = 0, mm_cum = 0;
-        u64 prevB = 0;
+        u64 prevB = 0, Bn = 0;
+        bool haveN = false;                      // the chunk behind the current one is in hand already
         for (int base = 0; base < maxlen; base += 64) {
             int n = imin(64, maxlen - base);
-            u64 B = (have0 && base == 0) ? B0 : w.mism_fwd(q0 + base, r0 + base, n);
+            u64 B;
+            if (have0 && base == 0) B = B0;
+            else if (haveN) { B = Bn; haveN = false; }
+            else {
+                // an extension that has not broken inside its first chunk is a long one (a closely related stretch): from
+                // here on two chunks a fetch -- four loads in flight, one memory wait per 128 symbols
+                const int n2 = imin(64, maxlen - base - 64);
+                if (base > 0 && n2 > 0) { w.mism2(q0 + base, r0 + base, 1, n, q0 + base + 64, r0 + base + 64, 1, n2, B, Bn); haveN = true; }
+                else B = w.mism_fwd(q0 + base, r0 + base, n);
+            }
             ExtMasks m = w.ext_scan(prevB, B, n);
+#if defined(LZANI_PATH_STATS) && defined(__HIP_DEVICE_COMPILE__)
+            w.ps[22] += 1;
+#endif
             u64 qm = m.qual;
             if (m.brk) qm &= lowmask(ctz64(m.brk) + 1);
             if (qm) {
@@ -747,14 +770,20 @@ struct PairMachine {
     // compare_ranges_both_ways folded (parser.cpp:251-374); len = literal run <= 64
     // fq / fr / nf / Bf: the first chunk of the forward extension behind the close match, fetched with the gap's two
     // diagonals where the policy can (haveF says whether it was)
-    LZ_HD void gap_fill(int ds, int r_left, int r_right_end, int len, int fq = 0, int fr = 0, int nf = 0, u64* Bf = nullptr, bool* haveF = nullptr)
+    // pre: the three masks already in hand (the policy's stretch_event fetched them with the event)
+    template <class PRE = NoStretch>
+    LZ_HD void gap_fill(int ds, int r_left, int r_right_end, int len, int fq = 0, int fr = 0, int nf = 0, u64* Bf = nullptr, bool* haveF = nullptr,
+                        const PRE* pre = nullptr)
     {
+        if (pre && pre->masks && Bf) { *Bf = pre->Bf; *haveF = true; }
         if (len <= 0) return;
         int to_scan = (r_right_end < r_left) ? len : imin(r_right_end - r_left, len);
         int shift = len - to_scan;
         u64 F = 0;
         if (to_scan > 0) {
             u64 Lm, Rm;
+            if (pre && pre->masks) { Lm = pre->Lm; Rm = pre->Rm; }
+            else
             if constexpr (wave_has_mism3<W>::value && !ALN) {
                 if (Bf) { w.mism3(ds, r_left, to_scan, ds + shift, r_right_end - to_scan, to_scan, fq, fr, nf, Lm, Rm, *Bf); *haveF = true; }
                 else w.mism2(ds, r_left, 1, to_scan, ds + shift, r_right_end - to_scan, 1, to_scan, Lm, Rm);
@@ -815,9 +844,45 @@ struct PairMachine {
                 }
             }
             w.stamp(4);
-            const bool hit = in_hand >= 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);   // (2, 4: the chain found the event)
+            typename stretch_type<W, wave_has_stretch<W>::value>::type pre;
+            pre.masks = false;
+            bool stretched = false;
+            int sc_kind = 0;
+            bool sc_hit = false;
+            if constexpr (wave_has_stretch_chain<W>::value && !ALN) {
+                // a run of close matches behind each other, by the hand-scheduled stretch chain: the events it takes are
+                // committed inside (the open region's accumulators, nl = 0 throughout); what ends the run comes back half
+                // done -- an extension that runs on, an anchor before the first seed step, a round without a seed
+                if (in_hand == 0 && trk && lit == 0 && g.nl == 0 && !w.chain_covers(i)) {
+                    u64 sc_Bf = 0;
+                    u32 sc_hq = 0;
+                    int sc_adv = 0;
+                    const int committed = w.stretch_chain(i, r_end, g.cl, g.clit, sc_kind, sc_Bf, sc_adv, sc_hq);
+                    if (committed || sc_kind == 1) prev_re = i;
+                    if (sc_kind == 1) {                      // gap and match are in: the rest of the forward extension
+                        w.stamp(5);
+                        const int e = extend_forward(i, r_end, true, sc_Bf);
+                        i += e; r_end += e;
+                        prev_re = i;
+                        continue;
+                    }
+                    if (sc_kind == 2) {                      // the anchor of that step, by the wave: it is the event if it exists
+                        int ap = 0, al = 0;
+                        w.anchor_by_wave(sc_hq, i + sc_adv, ap, al);
+                        if (ap != 0 && al >= P.msl) { adv = sc_adv; bpos = ap; blen = al; sc_hit = true; }
+                    }
+                }
+            }
+            if constexpr (wave_has_stretch<W>::value && !ALN) {
+                // behind a match, beyond everything the queue has detected (an extension moved: a related stretch)
+                if (!sc_hit && sc_kind != 3 && in_hand == 0 && trk && lit == 0 && !w.chain_covers(i)) stretched = w.stretch_event(i, iend - i, r_end, adv, bpos, blen, pre) != 0;
+            }
+            const bool hit = sc_hit || stretched || in_hand >= 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);   // (2, 4: the chain found the event)
 #if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
             w.st[6] += hit && in_hand != 2;
+#endif
+#if defined(LZANI_PATH_STATS) && defined(__HIP_DEVICE_COMPILE__)
+            w.ps[20] += hit; w.ps[21] += hit && (trk && lit + adv <= P.mqd && iabs(bpos - (r_end + lit + adv)) <= P.mrd);
 #endif
             i += adv; lit += adv;
             if (!hit) {
@@ -838,7 +903,7 @@ struct PairMachine {
                 // close match: fill the gap, then the match itself (parser.cpp:630-635; quirk Q2)
                 if constexpr (wave_has_mism3<W>::value && !ALN) {
                     fq = i + blen; fr = bpos + blen;
-                    gap_fill(i - lit, r_end, bpos + blen, lit, fq, fr, imax(0, imin(64, imin(D - fq, T - fr))), &Bf, &haveF);
+                    gap_fill(i - lit, r_end, bpos + blen, lit, fq, fr, imax(0, imin(64, imin(D - fq, T - fr))), &Bf, &haveF, &pre);
                 } else gap_fill(i - lit, r_end, bpos + blen, lit);
                 match_run(i, bpos, blen);
             } else {

@@ -28,6 +28,9 @@ __device__ unsigned long long g_chain_stats[24];
 #ifdef LZANI_PHASE_TIME
 __device__ unsigned long long g_phase_time[4];
 #endif
+#ifdef LZANI_PATH_STATS
+__device__ unsigned long long g_path_stats[36];
+#endif
 
 int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_t n, int begin_bit, int end_bit,
                     void* tmp, size_t* tmp_bytes, hipStream_t stream);      // lzani_sort.hip (hipCUB radix sort)
@@ -552,7 +555,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         // Query lists qualify when they are dense where they are: a query that occurs in a group of rows should meet a
         // good part of it (one matrix row read serves all its pairs of the group) -- the row x column blocks of a tiled
         // all2all do, the few relatives a kmer-db filter leaves per row do not.  No query twice in a row (one bitmap each).
-        const bool lists_ok = !query_ids || (!lists_dup && n_pairs >= 48 * lists_involved);
+        const char* sh = getenv("LZANI_PM_MIN_SHARE");
+        const u64 min_share = sh ? strtoull(sh, nullptr, 10) : 48;
+        const bool lists_ok = !query_ids || (!lists_dup && n_pairs >= min_share * lists_involved);
         pm = !rs && lists_ok && c->d_kmL && c->bk_stride && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 30 &&
              c->n >= 2 && n_rows >= min_rows && !(e && *e == '0');
         if (pm) {
@@ -926,6 +931,24 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             fprintf(stderr, "[lzani phase] pairs=%llu, s_memtime ticks per pair: whole pair %.0f, inside the null chain %.0f (%.1f %%), inside refill %.0f (%.1f %%)\n",
                     acc[3], (double)acc[0] / acc[3], (double)acc[1] / acc[3], 100.0 * acc[1] / acc[0], (double)acc[2] / acc[3], 100.0 * acc[2] / acc[0]);
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_phase_time), z, sizeof z));
+    }
+#endif
+#ifdef LZANI_PATH_STATS
+    {
+        unsigned long long acc[36], z[36] = {0};
+        HIPCHK(c, hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_path_stats), sizeof acc));
+        const char* nm[24] = {"find_event calls", "fe: seed straight from the chain's round", "fe: common call, plain candidate", "fe: light rounds", "fe: light round hit",
+                              "fe: light round without a hit", "fe: merge loop hit", "fe: jump to a plain candidate", "stretch calls", "stretch: not applicable",
+                              "stretch: no seed step", "stretch: anchor before the seed", "stretch: seed event", "stretch: ... with the masks", "stretch: sum of seed steps",
+                              "refills", "chain: nothing", "chain: round done", "chain: event found", "chain: seed event known", "events", "close events", "extension chunks", "stretch chain: events committed"};
+        fprintf(stderr, "[lzani paths] pairs=%llu, per pair:", (unsigned long long)n_pairs);
+        for (int k = 0; k < 24; ++k) fprintf(stderr, " %s=%.1f;", nm[k], (double)acc[k] / (double)n_pairs);
+        const char* wn[12] = {"-", "text end", "no seed step", "several window positions", "seed bounds", "match of 64+", "anchor before the seed", "tag in two slots / overflow",
+                              "anchor elsewhere", "extension runs on", "-", "-"};
+        fprintf(stderr, "\n[lzani paths] stretch chain exits per pair:");
+        for (int k = 1; k < 10; ++k) fprintf(stderr, " %s=%.1f;", wn[k], (double)acc[24 + k] / (double)n_pairs);
+        fprintf(stderr, "\n");
+        HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_path_stats), z, sizeof z));
     }
 #endif
 #ifdef LZANI_CHAIN_STATS

@@ -112,6 +112,15 @@ struct DevWave {
         stc_t0 = t;
     }
 #endif
+#ifdef LZANI_PATH_STATS                             // diagnostic build: which path found the events of a pair (LZ_PS slots, see lzani_hip.hip)
+    unsigned ps[24] = {0};
+    unsigned pw[12] = {0};                          // stretch chain: exits by reason
+#define LZ_PS(k) (ps[k] += 1)
+#define LZ_PSN(k, n) (ps[k] += (unsigned)(n))
+#else
+#define LZ_PS(k) ((void)0)
+#define LZ_PSN(k, n) ((void)0)
+#endif
 #ifdef LZANI_PHASE_TIME                             // slim diagnostic build: wave cycles inside the null chain / inside refill / per pair
     unsigned long long pt_chain = 0, pt_refill = 0;
     static __device__ __forceinline__ unsigned long long pt_now()
@@ -508,6 +517,7 @@ struct DevWave {
 #ifdef LZANI_PHASE_TIME
         const unsigned long long pt_r0 = pt_now();
 #endif
+        LZ_PS(15);
         u32* const cq = bitmap;                                 // (all zero again when refill returns)
         const int tb = I.kb - I.dirbits;
         scan_pos = imax(scan_pos, from);
@@ -856,7 +866,7 @@ struct DevWave {
         const u32* const rks = uniform_ptr(rkS);
         int code, ap, rec, t0, t1, t2, kb, kc, qh = q_head;
         u64 m, seed;
-#ifdef LZANI_STAMPS                         // (diagnostic build: the stamp bookkeeping makes the compiler lose sight of the uniformity)
+#if defined(LZANI_STAMPS) || defined(LZANI_PATH_STATS)    // (diagnostic builds: the bookkeeping makes the compiler lose sight of the uniformity)
         i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end); qh = __builtin_amdgcn_readfirstlane(qh);
         prev_rs = __builtin_amdgcn_readfirstlane(prev_rs); prev_re = __builtin_amdgcn_readfirstlane(prev_re);
         pre_lit = __builtin_amdgcn_readfirstlane(pre_lit);
@@ -1536,19 +1546,6 @@ struct DevWave {
 #ifdef LZANI_PHASE_TIME
         pt_chain += pt_now() - pt_t0;
 #endif
-#undef LZ_NC_LOADS_F
-#undef LZ_NC_LOADS_X
-#undef LZ_NC_ROUND_X
-#undef LZ_NC_ROUND_F
-#undef LZ_NC_ASM
-#undef LZ_NC_WORD7
-#undef LZ_NC_WORD7N
-#undef LZ_NC_WORD9
-#undef LZ_NC_WORD8
-#undef LZ_NC_FTURN
-#undef LZ_NC_FIX
-#undef LZ_NC_SEEDS
-#undef LZ_NC_COMMIT
         q_head = qh;
         if constexpr (JOIN) {
             // Nothing in hand because the queue ran out (or its tail does not cover the 41 steps behind i) while the pair's
@@ -1558,6 +1555,7 @@ struct DevWave {
             if (code == 0 && scan_pos >= i && scan_pos < iend && (qh >= q_cnt || (i > ilim && restart_at != i))) refill_only = true;
         }
         pre_round = code == 1;
+        if (code == 0) LZ_PS(16); else if (code == 1) LZ_PS(17); else if (code == 2) LZ_PS(18); else LZ_PS(19);
         pre_seed = seed; pre_rk0 = rk0; pre_rk1 = rk1; pre_qk = qk;
         if (code == 2) { adv = ap - i; last_src = q_head++; }
         if (code == 4) { adv = ap; last_src = -1; }          // the seed event: bpos, blen are the loop's
@@ -1578,11 +1576,445 @@ struct DevWave {
         return code;
     }
 
+    // The stretch chain (probe form; CHAIN parameters): runs of CLOSE matches behind each other -- what a related stretch is
+    // made of once an approximate extension has carried the scan beyond everything the queue has detected (scan_pos < i)
+    // -- as a second hand-scheduled loop next to the null chain, built from its parts: the tracking round (the three k-mer
+    // loads + the LDS bitmap, LZ_NC_LOADS / LZ_NC_ROUND), the seed event (one window position carries the first seed
+    // step's msl-mer, the 64 symbols behind it are real symbols of one strand and hold a mismatch) and the close match
+    // (gap fill by the best split's score, the match, the first chunk of the forward extension: parser.cpp:630-635,
+    // 251-374, 687-697) -- plus what the queue told the null chain and nothing tells this loop: whether a step up to the
+    // seed's has an ANCHOR (parser.cpp:585-602).  The steps' mixed mal-mer hashes ride with the round's loads, their tag
+    // words (one 4-byte probe per step up to the seed's) with the seed's verification; a tag hit at an earlier step, an
+    // overflowing bucket or a tag in two slots ends the run (the general path), a single hit at the seed's own step must
+    // be the seed itself (its bucket entry, one scalar load that flies with the close match's six: the arbitration of
+    // parser.cpp:604-623 then has nothing to decide).  State: i, r_end and the open region's accumulators (cl, clit; nl = 0
+    // before and after every event).  Stops with nothing half-done at the first event that is not this cycle; returns
+    // the number of events it committed.  ~125 vector + ~100 scalar instructions per event against ~330 + ~390 by the
+    // compiler's path (profiles/r4_related_*: the related kernel is bound by instruction issue, the scalar unit first).
+    static constexpr bool HAS_STRETCH_CHAIN = CHAIN != 0 && !JOIN && (ChainP<CHAIN>::MQD <= ChainP<CHAIN>::MRD);
+    // kind: 0 = nothing in hand; 1 = the last event's gap and match are committed, its forward extension is not: Bf = the
+    // mismatches of its first chunk (no break inside it); 2 = a step before the first seed step has an anchor candidate:
+    // step (adv) and its mixed hash (hq); 3 = the tracking steps of i hold no seed (their anchors decide: find_event)
+    __device__ __forceinline__ int stretch_chain(int& i, int& r_end, int& cl, int& clit, int& kind, u64& Bf, int& adv, u32& hqa)
+    {
+        typedef ChainP<CHAIN> CP;
+        enum { MQD = CP::MQD, MRD = CP::MRD, MSL = CP::MSL, AW = CP::AW, AM = CP::AM, AR = CP::AR, NT = CP::NT, WIN = CP::WIN };
+        const int ilim = iend - NT, rlim = R.len - MSL + 1 - WIN;
+        const u32 ldsb = (u32)(size_t)bitmap;
+        const u32 zero = 0, one = 1;
+        const u32* const qks = uniform_ptr(qkS);
+        const u32* const rks = uniform_ptr(rkS);
+        const u32* const qkl = uniform_ptr(qkL);
+        const u32* const rt2 = uniform_ptr(reinterpret_cast<const u32*>(R.t2));
+        const u32* const qt2 = uniform_ptr(reinterpret_cast<const u32*>(Q.t2));
+        const u32* const twp = uniform_ptr(I.tw);
+        const u32* const bkp = uniform_ptr(I.bk);
+        const int qend = __builtin_amdgcn_readfirstlane((R.nfree && Q.nfree) ? iend : -(1 << 30));
+        const int tbits = __builtin_amdgcn_readfirstlane(I.kb - I.dirbits), pbits = __builtin_amdgcn_readfirstlane(I.posbits);
+        const u32 tagm = (u32)__builtin_amdgcn_readfirstlane((int)I.tagmask);
+        int ncm, t0, t1, t2, kb, kc, gap, rec, cls, fok, blen, anc, aent;
+        u64 m, seed, m2, pmk;
+        u32 rk0, rk1, qk, hq, a0, a1, aq, t, bq, w1, dumv;
+#if defined(LZANI_STAMPS) || defined(LZANI_PATH_STATS)
+        i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end);
+        cl = __builtin_amdgcn_readfirstlane(cl); clit = __builtin_amdgcn_readfirstlane(clit);
+        const int ilim_u = __builtin_amdgcn_readfirstlane(ilim), rlim_u = __builtin_amdgcn_readfirstlane(rlim);
+#else
+        const int ilim_u = ilim, rlim_u = rlim;
+#endif
+#ifdef LZANI_PATH_STATS
+        int why = 0;
+#define LZ_SC_WHY(n) "s_mov_b32 %[why], " #n "\n\t"
+#define LZ_SC_WHY_OPERAND [why] "=&s"(why),
+#else
+#define LZ_SC_WHY(n)
+#define LZ_SC_WHY_OPERAND
+#endif
+#define LZ_SC_ASM(WORD) \
+        asm volatile( \
+            "s_mov_b32 %[ncm], 0\n\t" "s_mov_b32 %[kind], 0\n\t" LZ_SC_WHY(10) \
+            "v_add_u32_e32 %[w1], 64, %[lane]\n\t" \
+            "v_subrev_u32_e32 %[dumv], %[WIN], %[w1]\n\t" \
+            "v_min_u32_e32 %[w1], %[w1], %[dumv]\n\t" \
+            "v_add_u32_e32 %[dumv], %[wdum], %[lane]\n\t" \
+            "s_nop 3\n" \
+            "Lsc_top_%=:\n\t" \
+            LZ_SC_WHY(1) "s_cmp_gt_i32 %[i], %[ilim]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            LZ_SC_WHY(1) "s_cmp_gt_i32 %[rend], %[rlim]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            LZ_NC_LOADS_F \
+            "global_load_dword %[hq], %[a0], %[qkl]\n\t"    /* the steps' mixed mal-mer hashes */ \
+            "s_mov_b32 %[gap], %[NT]\n\t"                   /* (every tracking step counts: LZ_NC_SEEDS) */ \
+            LZ_NC_ROUND_F(WORD) \
+            LZ_NC_SEEDS \
+            LZ_SC_WHY(2) "s_cbranch_scc0 Lsc_noseed_%=\n\t"              /* no seed candidate at all: the anchors of all the steps (find_event, told so) */ \
+            LZ_NC_FIX \
+            LZ_SC_WHY(2) "s_cmp_eq_u64 %[m], 0\n\t" \
+            "s_cbranch_scc1 Lsc_noseed_%=\n\t" \
+            "s_ff1_i32_b64 %[t0], %[m]\n"                   /* l: the first step with a seed candidate */ \
+            "Lsc_sdl_%=:\n\t" \
+            "v_readlane_b32 %[t1], %[qk], %[t0]\n\t"        /* the step's msl-mer */ \
+            "s_add_i32 %[t2], %[t0], %[MRD]\n\t"            /* its window: the positions idx < l + mrd */ \
+            "s_sub_i32 %[kc], %[t2], 64\n\t" \
+            "s_max_i32 %[kc], %[kc], 0\n\t" \
+            "s_min_u32 %[kb], %[t2], 64\n\t" \
+            "s_sub_i32 %[kb], 64, %[kb]\n\t" \
+            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk1]\n\t" \
+            "s_bfm_b64 %[m2], %[kc], 0\n\t" \
+            "s_and_b64 %[m2], %[m2], vcc\n\t" \
+            "v_cmp_eq_u32_e32 vcc, %[t1], %[rk0]\n\t" \
+            "s_bcnt1_i32_b64 %[kc], %[m2]\n\t" \
+            "s_lshl_b64 vcc, vcc, %[kb]\n\t" \
+            "s_bcnt1_i32_b64 %[t1], vcc\n\t" \
+            "s_add_i32 %[t2], %[t1], %[kc]\n\t" \
+            "s_cmp_eq_u32 %[t2], 0\n\t" \
+            "s_cbranch_scc1 Lsc_sfalse_%=\n\t"              /* no window position: the prefilter's false candidate */ \
+            "s_cmp_lg_u32 %[t2], 1\n\t" \
+            LZ_SC_WHY(3) "s_cbranch_scc1 Lsc_end_%=\n\t"                 /* several window positions: the longest, then the nearest (general path) */ \
+            "s_ff1_i32_b64 %[t2], vcc\n\t" \
+            "s_sub_i32 %[t2], %[t2], %[kb]\n\t" \
+            "s_ff1_i32_b64 %[kc], %[m2]\n\t" \
+            "s_add_i32 %[kc], %[kc], 64\n\t" \
+            "s_cmp_lg_u32 %[t1], 0\n\t" \
+            "s_cselect_b32 %[t2], %[t2], %[kc]\n\t"         /* idx */ \
+            "s_add_i32 %[rec], %[rend], %[t2]\n\t"          /* the seed in the reference ... */ \
+            "s_add_i32 %[cls], %[i], %[t0]\n\t"             /* ... and in the query */ \
+            /* bounds as in the null chain's seed event: the 64 symbols behind the msl-mer inside the query and one strand */ \
+            "s_sub_i32 %[t1], %[qend], %[CQ64]\n\t" \
+            LZ_SC_WHY(4) "s_cmp_gt_i32 %[cls], %[t1]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            "s_sub_i32 %[t1], %[rlim], %[C41M]\n\t" \
+            "s_lshr_b32 %[t1], %[t1], 1\n\t"                /* L */ \
+            "s_add_i32 %[t2], %[rec], %[MSL64]\n\t" \
+            "s_cmp_le_i32 %[t2], %[t1]\n\t" \
+            "s_cbranch_scc1 Lsc_sok_%=\n\t" \
+            "s_add_i32 %[kb], %[t1], %[C2MRD]\n\t"          /* rc0 */ \
+            "s_cmp_lt_i32 %[rec], %[kb]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            "s_add_i32 %[kb], %[kb], %[t1]\n\t" \
+            "s_cmp_gt_i32 %[t2], %[kb]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n" \
+            "Lsc_sok_%=:\n\t" \
+            /* the seed's verification window and, with it, the tag words of the steps 0 .. l */ \
+            "s_add_i32 %[t1], %[rec], %[MSL]\n\t" \
+            "s_add_i32 %[t2], %[cls], %[MSL]\n\t" \
+            "v_add_u32_e32 %[a0], %[t1], %[lane]\n\t" \
+            "v_add_u32_e32 %[a1], %[t2], %[lane]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], 4, %[a0]\n\t" \
+            "v_lshrrev_b32_e32 %[t], 4, %[a1]\n\t" \
+            "v_lshrrev_b32_e32 %[bq], %[TB], %[hq]\n\t"     /* the step's bucket */ \
+            "v_cmp_ge_u32_e32 vcc, %[t0], %[lane]\n\t"      /* the steps up to the seed's */ \
+            "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t" \
+            "v_lshlrev_b32_e32 %[t], 2, %[t]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], 2, %[bq]\n\t" \
+            "v_cndmask_b32_e32 %[bq], 0, %[bq], vcc\n\t" \
+            "global_load_dword %[aq], %[aq], %[rt2]\n\t" \
+            "global_load_dword %[t], %[t], %[qt2]\n\t" \
+            "s_mov_b64 %[pmk], vcc\n\t" \
+            "s_nop 0\n\t" \
+            "global_load_dword %[bq], %[bq], %[twp]\n\t" \
+            "v_and_b32_e32 %[a0], 15, %[a0]\n\t" \
+            "v_and_b32_e32 %[a1], 15, %[a1]\n\t" \
+            "v_lshlrev_b32_e32 %[a0], 1, %[a0]\n\t" \
+            "v_lshlrev_b32_e32 %[a1], 1, %[a1]\n\t" \
+            "s_waitcnt vmcnt(0)\n\t" \
+            "v_lshrrev_b32_e32 %[aq], %[a0], %[aq]\n\t" \
+            "v_lshrrev_b32_e32 %[t], %[a1], %[t]\n\t" \
+            "v_xor_b32_e32 %[aq], %[aq], %[t]\n\t" \
+            "v_and_b32_e32 %[aq], 3, %[aq]\n\t" \
+            "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t" \
+            /* anchor candidates: a zero byte in w ^ rep4(0x80 | tag) = a slot of the bucket carrying the step's tag */ \
+            "v_and_b32_e32 %[a0], %[TAGM], %[hq]\n\t" \
+            "v_or_b32_e32 %[a0], 0x80, %[a0]\n\t" \
+            "v_perm_b32 %[a0], %[a0], %[a0], %[zero]\n\t" \
+            "v_xor_b32_e32 %[a0], %[a0], %[bq]\n\t"         /* x */ \
+            "v_subrev_u32_e32 %[a1], 0x01010101, %[a0]\n\t" \
+            "v_not_b32_e32 %[a0], %[a0]\n\t" \
+            "v_and_b32_e32 %[a1], %[a1], %[a0]\n\t" \
+            "v_and_b32_e32 %[a1], 0x80808080, %[a1]\n\t"    /* z: its lowest flag is exact */ \
+            "s_cmp_eq_u64 %[m], 0\n\t" \
+            LZ_SC_WHY(5) "s_cbranch_scc1 Lsc_end_%=\n\t"                 /* 64 more symbols match: the general path measures on */ \
+            "s_ff1_i32_b64 %[blen], %[m]\n\t" \
+            "s_add_i32 %[blen], %[blen], %[MSL]\n\t" \
+            "v_cmp_ne_u32_e32 vcc, 0, %[a1]\n\t" \
+            "s_mov_b64 %[m2], vcc\n\t" \
+            "v_cmp_eq_u32_e32 vcc, 0x808080ff, %[bq]\n\t"   /* an overflowing bucket (TW_OVERFLOW) */ \
+            "s_or_b64 %[m2], %[m2], vcc\n\t" \
+            "s_and_b64 %[m2], %[m2], %[pmk]\n\t"            /* the steps <= l with an anchor candidate */ \
+            "s_bfm_b64 %[seed], %[t0], 0\n\t" \
+            "s_and_b64 %[seed], %[seed], %[m2]\n\t" \
+            "s_cmp_lg_u64 %[seed], 0\n\t" \
+            LZ_SC_WHY(6) "s_cbranch_scc1 Lsc_anchor_%=\n\t"              /* ... at a step before the seed's: that anchor is the event (handed over) */ \
+            "s_mov_b32 %[anc], 0\n\t" \
+            "s_cmp_eq_u64 %[m2], 0\n\t" \
+            "s_cbranch_scc1 Lsc_noanc_%=\n\t" \
+            /* at the seed's own step: the entry behind the tag must be the seed itself */ \
+            "v_readlane_b32 %[kc], %[a1], %[t0]\n\t"        /* z */ \
+            "v_readlane_b32 %[t1], %[bq], %[t0]\n\t"        /* w */ \
+            "v_readlane_b32 %[t2], %[hq], %[t0]\n\t" \
+            "s_cmp_eq_u32 %[t1], 0x808080ff\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            "s_sub_u32 %[t1], %[kc], 1\n\t" \
+            "s_and_b32 %[t1], %[t1], %[kc]\n\t" \
+            "s_cmp_lg_u32 %[t1], 0\n\t" \
+            LZ_SC_WHY(7) "s_cbranch_scc1 Lsc_end_%=\n\t"                 /* the tag in two slots */ \
+            "s_ff1_i32_b32 %[kc], %[kc]\n\t" \
+            "s_lshr_b32 %[kc], %[kc], 3\n\t"                /* the slot */ \
+            "s_lshr_b32 %[t2], %[t2], %[TB]\n\t" \
+            "s_lshl_b32 %[t2], %[t2], 2\n\t" \
+            "s_add_u32 %[t2], %[t2], %[kc]\n\t" \
+            "s_lshl_b32 %[t2], %[t2], 2\n\t" \
+            "s_load_dword %[aent], %[bkp], %[t2]\n\t" \
+            "s_mov_b32 %[anc], 1\n" \
+            "Lsc_noanc_%=:\n\t" \
+            /* The close match (as in the null chain): t0 = l, rec / cls = the seed in the reference / query, t1 = fq, fok = fr */ \
+            "s_add_i32 %[t1], %[cls], %[blen]\n\t" \
+            "s_add_i32 %[t2], %[t1], 64\n\t" \
+            "s_sub_i32 %[kb], %[qend], %[C40M]\n\t"         /* Lq */ \
+            "s_cmp_gt_i32 %[t2], %[kb]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            "s_add_i32 %[fok], %[rec], %[blen]\n\t" \
+            "s_add_i32 %[t2], %[fok], 64\n\t"               /* the reference side: [rend, fr + 64) on one strand */ \
+            "s_sub_i32 %[kb], %[rlim], %[C41M]\n\t" \
+            "s_lshr_b32 %[kb], %[kb], 1\n\t"                /* L */ \
+            "s_cmp_le_i32 %[t2], %[kb]\n\t" \
+            "s_cbranch_scc1 Lsc_hull_%=\n\t" \
+            "s_add_i32 %[kc], %[kb], %[C2MRD]\n\t"          /* rc0 */ \
+            "s_cmp_lt_i32 %[rend], %[kc]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            "s_add_i32 %[kc], %[kc], %[kb]\n\t" \
+            "s_cmp_gt_i32 %[t2], %[kc]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n" \
+            "Lsc_hull_%=:\n\t" \
+            "s_sub_i32 %[kb], %[fok], %[rend]\n\t" \
+            "s_min_i32 %[kb], %[kb], %[t0]\n\t"             /* to_scan */ \
+            "s_sub_i32 %[kc], %[t0], %[kb]\n\t" \
+            "s_sub_i32 %[gap], %[fok], %[kb]\n\t"           /* right diagonal: reference start */ \
+            "s_add_i32 %[kc], %[kc], %[i]\n\t"              /*                 query start */ \
+            "v_add_u32_e32 %[rk0], %[rend], %[lane]\n\t" \
+            "v_add_u32_e32 %[rk1], %[i], %[lane]\n\t" \
+            "v_add_u32_e32 %[qk], %[gap], %[lane]\n\t" \
+            "v_add_u32_e32 %[a0], %[kc], %[lane]\n\t" \
+            "v_add_u32_e32 %[a1], %[fok], %[lane]\n\t" \
+            "v_add_u32_e32 %[aq], %[t1], %[lane]\n\t" \
+            "v_lshrrev_b32_e32 %[rk0], 4, %[rk0]\n\t" \
+            "v_lshrrev_b32_e32 %[rk1], 4, %[rk1]\n\t" \
+            "v_lshrrev_b32_e32 %[qk], 4, %[qk]\n\t" \
+            "v_lshrrev_b32_e32 %[a0], 4, %[a0]\n\t" \
+            "v_lshrrev_b32_e32 %[a1], 4, %[a1]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], 4, %[aq]\n\t" \
+            "v_lshlrev_b32_e32 %[rk0], 2, %[rk0]\n\t" \
+            "v_lshlrev_b32_e32 %[rk1], 2, %[rk1]\n\t" \
+            "v_lshlrev_b32_e32 %[qk], 2, %[qk]\n\t" \
+            "v_lshlrev_b32_e32 %[a0], 2, %[a0]\n\t" \
+            "v_lshlrev_b32_e32 %[a1], 2, %[a1]\n\t" \
+            "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t" \
+            "s_nop 0\n\t" \
+            "global_load_dword %[rk0], %[rk0], %[rt2]\n\t" \
+            "global_load_dword %[rk1], %[rk1], %[qt2]\n\t" \
+            "global_load_dword %[qk], %[qk], %[rt2]\n\t" \
+            "global_load_dword %[a0], %[a0], %[qt2]\n\t" \
+            "global_load_dword %[a1], %[a1], %[rt2]\n\t" \
+            "global_load_dword %[aq], %[aq], %[qt2]\n\t" \
+            "s_bfm_b64 %[seed], %[kb], 0\n\t"               /* the to_scan lanes of the gap's diagonals */ \
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+            /* the anchor at the seed's step, if there is one, must sit at the seed's position */ \
+            "s_cmp_eq_u32 %[anc], 0\n\t" \
+            "s_cbranch_scc1 Lsc_anok_%=\n\t" \
+            "s_bfm_b32 %[anc], %[PB], 0\n\t" \
+            "s_and_b32 %[aent], %[aent], %[anc]\n\t" \
+            LZ_SC_WHY(8) "s_cmp_lg_u32 %[aent], %[rec]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n" \
+            "Lsc_anok_%=:\n\t" \
+            /* left diagonal -> m = its matches */ \
+            "v_add_u32_e32 %[t], %[rend], %[lane]\n\t" \
+            "v_add_u32_e32 %[bq], %[i], %[lane]\n\t" \
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t" \
+            "v_and_b32_e32 %[t], 30, %[t]\n\t" \
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t" \
+            "v_lshrrev_b32_e32 %[rk0], %[t], %[rk0]\n\t" \
+            "v_lshrrev_b32_e32 %[rk1], %[bq], %[rk1]\n\t" \
+            "v_xor_b32_e32 %[rk0], %[rk0], %[rk1]\n\t" \
+            "v_and_b32_e32 %[rk0], 3, %[rk0]\n\t" \
+            "v_cmp_eq_u32_e64 %[m], 0, %[rk0]\n\t" \
+            /* right diagonal -> m2 */ \
+            "v_add_u32_e32 %[t], %[gap], %[lane]\n\t" \
+            "v_add_u32_e32 %[bq], %[kc], %[lane]\n\t" \
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t" \
+            "v_and_b32_e32 %[t], 30, %[t]\n\t" \
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t" \
+            "v_lshrrev_b32_e32 %[qk], %[t], %[qk]\n\t" \
+            "v_lshrrev_b32_e32 %[a0], %[bq], %[a0]\n\t" \
+            "v_xor_b32_e32 %[qk], %[qk], %[a0]\n\t" \
+            "v_and_b32_e32 %[qk], 3, %[qk]\n\t" \
+            "v_cmp_eq_u32_e64 %[m2], 0, %[qk]\n\t" \
+            /* forward chunk -> vcc = its MISmatches */ \
+            "v_add_u32_e32 %[t], %[fok], %[lane]\n\t" \
+            "v_add_u32_e32 %[bq], %[t1], %[lane]\n\t" \
+            "v_lshlrev_b32_e32 %[t], 1, %[t]\n\t" \
+            "v_lshlrev_b32_e32 %[bq], 1, %[bq]\n\t" \
+            "v_and_b32_e32 %[t], 30, %[t]\n\t" \
+            "v_and_b32_e32 %[bq], 30, %[bq]\n\t" \
+            "v_lshrrev_b32_e32 %[a1], %[t], %[a1]\n\t" \
+            "v_lshrrev_b32_e32 %[aq], %[bq], %[aq]\n\t" \
+            "v_xor_b32_e32 %[a1], %[a1], %[aq]\n\t" \
+            "v_and_b32_e32 %[a1], 3, %[a1]\n\t" \
+            "v_cmp_ne_u32_e32 vcc, 0, %[a1]\n\t" \
+            "s_and_b64 %[m], %[m], %[seed]\n\t"             /* Lm */ \
+            "s_and_b64 %[m2], %[m2], %[seed]\n\t"           /* Rm */ \
+            "s_mov_b64 %[seed], vcc\n\t"                    /* Bf */ \
+            /* best split: lane s scores popc(Lm below s) + popc(Rm from s on) for s <= to_scan; the maximum is what counts */ \
+            "s_bcnt1_i32_b64 %[t2], %[m2]\n\t" \
+            "s_mov_b64 vcc, %[m]\n\t" \
+            "s_nop 0\n\t" \
+            "v_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\t" \
+            "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t" \
+            "s_mov_b64 vcc, %[m2]\n\t" \
+            "s_nop 0\n\t" \
+            "v_mbcnt_lo_u32_b32 %[bq], vcc_lo, 0\n\t" \
+            "v_mbcnt_hi_u32_b32 %[bq], vcc_hi, %[bq]\n\t" \
+            "v_add_u32_e32 %[t], %[t2], %[t]\n\t" \
+            "v_sub_u32_e32 %[t], %[t], %[bq]\n\t" \
+            "v_cmp_ge_u32_e32 vcc, %[kb], %[lane]\n\t" \
+            "s_nop 1\n\t" \
+            "v_cndmask_b32_e32 %[t], 0, %[t], vcc\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+            "s_nop 1\n\t" \
+            "v_max_u32_dpp %[t], %[t], %[t] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+            "s_nop 1\n\t" \
+            "v_readlane_b32 %[t2], %[t], 63\n\t"            /* score */ \
+            /* the forward extension's first chunk (try_extend_forward, parser.cpp:377-409) */ \
+            "s_mov_b64 vcc, %[seed]\n\t" \
+            "s_lshl_b32 %[gap], vcc_lo, %[AW1]\n\t" \
+            "s_lshr_b32 %[kb], vcc_lo, %[AW1C]\n\t" \
+            "s_lshl_b32 %[kc], vcc_hi, %[AW1]\n\t" \
+            "s_or_b32 %[kc], %[kc], %[kb]\n\t" \
+            "s_lshr_b32 %[kb], vcc_hi, %[AW1C]\n\t" \
+            "v_mov_b32_e32 %[rk0], %[gap]\n\t" \
+            "v_mov_b32_e32 %[rk1], %[kc]\n\t" \
+            "v_mov_b32_e32 %[qk], %[kb]\n\t" \
+            "v_cmp_gt_u32_e32 vcc, 32, %[lane]\n\t" \
+            "v_alignbit_b32 %[a0], %[rk1], %[rk0], %[lane]\n\t" \
+            "v_alignbit_b32 %[a1], %[qk], %[rk1], %[lane]\n\t" \
+            "v_cndmask_b32_e32 %[a0], %[a1], %[a0], vcc\n\t" \
+            "v_and_b32_e32 %[a0], %[AWM], %[a0]\n\t" \
+            "v_bcnt_u32_b32 %[a1], %[a0], 0\n\t" \
+            "v_and_b32_e32 %[a0], %[ARM], %[a0]\n\t" \
+            "v_cmp_lt_u32_e32 vcc, %[AM], %[a1]\n\t"            /* brk */ \
+            "v_cmp_eq_u32_e64 %[m], 0, %[a0]\n\t"           /* qual */ \
+            "s_nop 0\n\t" \
+            "s_cmp_eq_u64 vcc, 0\n\t" \
+            LZ_SC_WHY(9) "s_cbranch_scc1 Lsc_extgo_%=\n\t"               /* no break inside the chunk: gap and match committed, the extension handed over */ \
+            "s_ff1_i32_b64 %[kb], vcc\n\t" \
+            LZ_SC_WHY(9) "s_cmp_ge_u32 %[kb], 63\n\t" \
+            "s_cbranch_scc1 Lsc_extgo_%=\n\t" \
+            "s_add_i32 %[kb], %[kb], 1\n\t" \
+            "s_bfm_b64 %[m2], %[kb], 0\n\t" \
+            "s_and_b64 %[m], %[m], %[m2]\n\t"               /* qualifying symbols up to the break */ \
+            "s_mov_b32 %[kb], 0\n\t"                         /* e */ \
+            "s_mov_b32 %[kc], 0\n\t"                         /* mm */ \
+            "s_cbranch_scc0 Lsc_sext_%=\n\t" \
+            "s_flbit_i32_b64 %[kb], %[m]\n\t" \
+            "s_sub_i32 %[kb], 64, %[kb]\n\t"                /* e = the last qualifying symbol + 1 */ \
+            "s_bfm_b64 %[m2], %[kb], 0\n\t" \
+            "s_and_b64 %[m2], %[m2], %[seed]\n\t" \
+            "s_bcnt1_i32_b64 %[kc], %[m2]\n"                 /* mm: the mismatches among its e symbols */ \
+            "Lsc_sext_%=:\n\t" \
+            /* commit: the open region grows by the gap (score matches, l - score literals), the match, the extension */ \
+            "s_add_i32 %[cl], %[cl], %[t2]\n\t" \
+            "s_add_i32 %[cl], %[cl], %[blen]\n\t" \
+            "s_add_i32 %[cl], %[cl], %[kb]\n\t" \
+            "s_sub_i32 %[cl], %[cl], %[kc]\n\t" \
+            "s_add_i32 %[clit], %[clit], %[t0]\n\t" \
+            "s_sub_i32 %[clit], %[clit], %[t2]\n\t" \
+            "s_add_i32 %[clit], %[clit], %[kc]\n\t" \
+            "s_add_i32 %[i], %[t1], %[kb]\n\t" \
+            "s_add_i32 %[rend], %[fok], %[kb]\n\t" \
+            "s_add_i32 %[ncm], %[ncm], 1\n\t" \
+            "s_branch Lsc_top_%=\n" \
+            "Lsc_sfalse_%=:\n\t" \
+            LZ_SC_WHY(2) "s_bitset0_b64 %[m], %[t0]\n\t" \
+            "s_cmp_eq_u64 %[m], 0\n\t" \
+            "s_cbranch_scc1 Lsc_noseed_%=\n\t" \
+            "s_ff1_i32_b64 %[t0], %[m]\n\t" \
+            "s_branch Lsc_sdl_%=\n" \
+            "Lsc_noseed_%=:\n\t" \
+            "s_mov_b32 %[kind], 3\n\t" \
+            "s_branch Lsc_end_%=\n" \
+            "Lsc_anchor_%=:\n\t"                           /* the first step with an anchor candidate and its hash */ \
+            "s_ff1_i32_b64 %[t0], %[seed]\n\t" \
+            "v_readlane_b32 %[t1], %[hq], %[t0]\n\t" \
+            "s_mov_b32 %[kind], 2\n\t" \
+            "s_branch Lsc_end_%=\n" \
+            "Lsc_extgo_%=:\n\t"                            /* the gap (score matches, l - score literals) and the match; Bf = seed */ \
+            "s_add_i32 %[cl], %[cl], %[t2]\n\t" \
+            "s_add_i32 %[cl], %[cl], %[blen]\n\t" \
+            "s_add_i32 %[clit], %[clit], %[t0]\n\t" \
+            "s_sub_i32 %[clit], %[clit], %[t2]\n\t" \
+            "s_mov_b32 %[i], %[t1]\n\t" \
+            "s_mov_b32 %[rend], %[fok]\n\t" \
+            "s_mov_b32 %[kind], 1\n" \
+            "Lsc_end_%=:\n\t" \
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+            "s_nop 4" \
+            : LZ_SC_WHY_OPERAND [i] "+s"(i), [rend] "+s"(r_end), [cl] "+s"(cl), [clit] "+s"(clit), [ncm] "=&s"(ncm), \
+              [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [gap] "=&s"(gap), [rec] "=&s"(rec), [cls] "=&s"(cls), \
+              [fok] "=&s"(fok), [blen] "=&s"(blen), [anc] "=&s"(anc), [aent] "=&s"(aent), [kind] "=&s"(kind), [m] "=&s"(m), [seed] "=&s"(seed), [m2] "=&s"(m2), [pmk] "=&s"(pmk), \
+              [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [hq] "=&v"(hq), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), \
+              [w1] "=&v"(w1), [dumv] "=&v"(dumv) \
+            : [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [qkl] "s"(qkl), [rt2] "s"(rt2), [qt2] "s"(qt2), [twp] "s"(twp), [bkp] "s"(bkp), \
+              [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS), [TB] "s"(tbits), [PB] "s"(pbits), [TAGM] "s"(tagm), \
+              [lane] "v"(lane), [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one), \
+              [MRD] "n"(MRD), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64), [MSL] "n"(MSL), [MSL64] "n"(MSL + 64), \
+              [C41M] "n"(3 * MRD + 1 - WIN - MSL), [C40M] "n"(MRD - MSL), [CQ64] "n"(MRD + 64), [C2MRD] "n"(2 * MRD), \
+              [AW1] "n"(AW - 1), [AW1C] "n"(33 - AW), [AWM] "n"((1 << AW) - 1), [ARM] "n"(((1 << AR) - 1) << (AW - AR)), [AM] "n"(AM), [KS5] "n"(2 * MSL + 5), [KS] "n"(2 * MSL) \
+            : "vcc", "scc", "memory");
+        if constexpr (MSL == 9) { LZ_SC_ASM(LZ_NC_WORD9) }
+        else if constexpr (MSL == 8) { LZ_SC_ASM(LZ_NC_WORD8) }
+        else { LZ_SC_ASM(LZ_NC_WORD7) }
+#undef LZ_SC_ASM
+        last_src = -1;
+        Bf = seed; adv = t0; hqa = (u32)t1;
+        LZ_PSN(23, ncm);
+#ifdef LZANI_PATH_STATS
+        pw[why < 12 ? why : 0] += 1;
+#endif
+#undef LZ_SC_WHY
+#undef LZ_SC_WHY_OPERAND
+        return ncm;
+    }
+#undef LZ_NC_LOADS_F
+#undef LZ_NC_LOADS_X
+#undef LZ_NC_ROUND_X
+#undef LZ_NC_ROUND_F
+#undef LZ_NC_ASM
+#undef LZ_NC_WORD7
+#undef LZ_NC_WORD7N
+#undef LZ_NC_WORD9
+#undef LZ_NC_WORD8
+#undef LZ_NC_FTURN
+#undef LZ_NC_FIX
+#undef LZ_NC_SEEDS
+#undef LZ_NC_COMMIT
+
     __device__ __forceinline__ bool find_event(int i, int n, bool trk, int r_end, int lit, int& adv, int& bpos, int& blen)
     {
         if (!FAST || !BK || P.mqd + P.mrd > 128)                     // other index forms, wide seed windows: rounds
             return find_event_round(i, n, trk, r_end, lit, adv, bpos, blen);
         last_src = -1;
+        LZ_PS(0);
         // tracking steps of this call (the machine clears trk once lit > mqd); one lane per tracking step
         const int nt = trk ? imin(imin(n, P.mqd - lit + 1), 64) : 0;
         if (q_head < q_cnt && __builtin_amdgcn_readlane(a_pos, q_head) < i) drop_before(i);
@@ -1609,6 +2041,7 @@ struct DevWave {
                     if (popc64(d0) + popc64(d1) == 1) {
                         const int idx = d0 ? ctz64(d0) : 64 + ctz64(d1);
                         adv = ls; bpos = r_end + idx; blen = wave_equal_len(bpos, i + ls, P.msl);
+                        LZ_PS(1);
                         return true;
                     }
                 }
@@ -1627,6 +2060,7 @@ struct DevWave {
                     adv = __builtin_amdgcn_readlane(a_pos, q_head) - i;
                     bpos = (int)((u32)__builtin_amdgcn_readlane((int)a_ref, q_head)); blen = plen;
                     last_src = q_head++;
+                    LZ_PS(2);
                     return true;
                 }
             }
@@ -1642,6 +2076,7 @@ struct DevWave {
             // (the steps' mal-mer hashes with the round's own loads: the anchor of a step then needs no fetch of its own
             // before its bucket -- one memory round trip less per event of a related stretch)
             const u32 hqv = qkL[(u32)(i + lane)];
+            LZ_PS(3);
             seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk);
             // The anchors of the steps are probed only as far as they can matter: up to the first step with a seed
             // candidate (a seed is an event: nothing behind it is reached), else the first eight steps, the rest only if
@@ -1676,8 +2111,9 @@ struct DevWave {
                     }
                 }
                 arbitrate(P, R.len, lit + l, ap, al, sp, sl);
-                if (sl >= P.msl) { adv = l; bpos = sp; blen = sl; return true; }
+                if (sl >= P.msl) { adv = l; bpos = sp; blen = sl; LZ_PS(4); return true; }
             }
+            LZ_PS(5);
             if (lit + nt <= P.mqd) { adv = nt; return false; }       // mqd = 64: one more tracking step in the next call
             // no tracking step hits: on in lost mode; whatever the queue still holds of these steps goes
             pos = i + nt;
@@ -1727,6 +2163,7 @@ struct DevWave {
                         if (sl >= P.msl) {
                             adv = l; bpos = sp; blen = sl;
                             if (src >= 0) note_src(src, ap, al, sp, sl);
+                            LZ_PS(6);
                             return true;
                         }
                     }
@@ -1746,6 +2183,7 @@ struct DevWave {
             if (__builtin_expect(plen > 0, 1)) {                     // a plain candidate: the event, whatever kind of step it is
                 adv = qp - i; bpos = (int)((u32)__builtin_amdgcn_readlane((int)a_ref, q_head)); blen = plen;
                 last_src = q_head++;
+                LZ_PS(7);
                 return true;
             }
             int ap, al;
@@ -1760,6 +2198,159 @@ struct DevWave {
         }
         adv = n;
         return false;
+    }
+    // ---- related stretches: the event behind a match straight from the packed texts --------------------------------
+    // Where an approximate extension has carried the scan beyond everything the queue has detected (scan_pos < i: the
+    // pairs a kmer-db filter leaves consist of such stretches), find_event's light round costs a chain of dependent
+    // fetches per event: k-mer words of the steps and of the window, tag words, the bucket, the anchor's text, the seed's
+    // text, then the gap fill's diagonals and the first chunk of the forward extension -- and this kernel, on related
+    // pairs, waits for memory (profiles/r4_related_base_*: 19.8 k L2 misses and 1.9 M wave cycles per pair, 57 % of them
+    // waiting).  Here the event comes out of TWO round trips (N-free pair, the window inside one strand):
+    //   1. every lane fetches 32 symbols of the query from its step on and 32 symbols of the reference from its window
+    //      position(s) on (three dwords each, the same few lines for the whole wave): the msl-mers of steps and window,
+    //      the steps' mal-mer hashes and the first 32 symbols of every seed's match length are then arithmetic on
+    //      registers (no k-mer words: 16 x fewer lines than the u32-per-position arrays);
+    //   2. the buckets of the steps up to the first seed step (read whole: no tag-word probe in front) TOGETHER with what
+    //      the close match will need if the seed stands -- the right diagonal of its gap fill and the first chunk of its
+    //      forward extension; the left diagonal is the step diagonal of trip 1.
+    // The anchors then confirm the speculation (an anchor at an earlier step, or one that wins the arbitration at the
+    // seed's step, makes the event theirs and the masks void).  Semantics: exactly find_event's for the same call
+    // (parser.cpp:533-624); anything outside the simple geometry returns 0 with nothing touched.
+    static constexpr bool HAS_STRETCH = FAST && BK;
+    struct Stretch { bool masks; u64 Lm, Rm, Bf; int to_scan, nf; };
+    __device__ __forceinline__ int stretch_event(int i, int n, int r_end, int& adv, int& bpos, int& blen, Stretch& ev)
+    {
+        ev.masks = false;
+        const int nt = P.mqd + 1, W = P.mqd + P.mrd;
+        const bool strand = (r_end + 160 <= R.L) | ((r_end >= R.rc0) & (r_end + 160 <= R.rc0 + R.L));
+        LZ_PS(8);
+        if (!(R.nfree && Q.nfree) || P.mqd > 63 || W > 128 || n < nt || i + 96 > Q.L || r_end < 0 || !strand) { LZ_PS(9); return 0; }
+        last_src = -1;
+        // trip 1: 32 symbols per lane from step i + lane, window positions r_end + lane and r_end + 64 + lane
+        const u32* const q32 = reinterpret_cast<const u32*>(Q.t2);
+        const u32* const r32 = reinterpret_cast<const u32*>(R.t2);
+        const u32 qa = (u32)(i + lane), ra = (u32)(r_end + lane);
+        u32 q0 = q32[qa >> 4], q1 = q32[(qa >> 4) + 1], q2 = q32[(qa >> 4) + 2];
+        u32 a0 = r32[ra >> 4], a1 = r32[(ra >> 4) + 1], a2 = r32[(ra >> 4) + 2];
+        u32 b0 = r32[(ra >> 4) + 4], b1 = r32[(ra >> 4) + 5], b2 = r32[(ra >> 4) + 6];
+        // (bitmap forms: which of the steps have an anchor candidate at all is in the pair's candidate bitmap -- two words of
+        // it with the same trip; the probe form asks the buckets of all steps up to the seed's)
+        unsigned long long cw = 0;
+        if (JOIN) cw = cand_bits[((u32)i >> 6) + (u32)imin(lane, 1)];
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(cw));
+        const u32 sq = (qa & 15u) * 2u, sa = (ra & 15u) * 2u;
+        const u32 wql = __builtin_amdgcn_alignbit(q1, q0, sq), wqh = __builtin_amdgcn_alignbit(q2, q1, sq);
+        const u32 w0l = __builtin_amdgcn_alignbit(a1, a0, sa), w0h = __builtin_amdgcn_alignbit(a2, a1, sa);
+        const u32 w1l = __builtin_amdgcn_alignbit(b1, b0, sa), w1h = __builtin_amdgcn_alignbit(b2, b1, sa);
+        // close seeds: the window's msl-mers into the LDS bitmap, every step tests its own (seed_prefilter)
+        const u32 km = (u32)lowmask(2 * P.msl);
+        const u32 qk = wql & km, rk0 = w0l & km, rk1 = w1l & km;
+        u64 seedmask;
+        {
+            const bool vq = lane < nt, v0 = lane < W, v1 = lane + 64 < W;
+            const u32 hq_ = P.msl <= 7 ? qk : (qk * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
+            const u32 h0 = P.msl <= 7 ? rk0 : (rk0 * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
+            const u32 h1 = P.msl <= 7 ? rk1 : (rk1 * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
+            const u32 scratch = (u32)lane;
+            const u32 x0 = v0 ? h0 >> 5 : scratch, x1 = v1 ? h1 >> 5 : scratch, xq = vq ? hq_ >> 5 : scratch;
+            atomicOr(&bitmap[x0], v0 ? 1u << (h0 & 31) : 0u);
+            atomicOr(&bitmap[x1], v1 ? 1u << (h1 & 31) : 0u);
+            lds_order();
+            const bool hit = vq & ((bitmap[xq] >> (hq_ & 31)) & 1u);
+            lds_order();
+            bitmap[x0] = 0;
+            bitmap[x1] = 0;
+            seedmask = wballot(hit);
+        }
+        // the first step with a real seed candidate (the bitmap holds the whole window, a step may use its first l + mrd positions)
+        int l = -1;
+        u64 d0 = 0, d1 = 0;
+        for (int it = 0; it < 64 && seedmask; ++it) {
+            const int s = ctz64(seedmask);
+            seedmask &= seedmask - 1;
+            const u32 qkl = (u32)__builtin_amdgcn_readlane((int)qk, s);
+            d0 = wballot(rk0 == qkl) & lowmask(s + P.mrd);
+            d1 = wballot(rk1 == qkl) & lowmask(s + P.mrd - 64);
+            if (d0 | d1) { l = s; break; }
+        }
+        if (l < 0) { LZ_PS(10); return 0; }   // no seed within the tracking steps: the anchors of all of them (find_event)
+        // its candidates: the first 32 symbols of each match from the registers
+        const int qp = i + l, ref_pred = r_end + l;
+        const u64 wq = bcast64(((u64)wqh << 32) | wql, l);
+        int sp = 0, sl = 0;
+        for (int it = 0; it < 130 && (d0 | d1); ++it) {
+            int idx;
+            if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
+            else { idx = 64 + ctz64(d1); d1 &= d1 - 1; }
+            const u64 wr = idx < 64 ? bcast64(((u64)w0h << 32) | w0l, idx) : bcast64(((u64)w1h << 32) | w1l, idx - 64);
+            const u64 x = wq ^ wr, d = (x | (x >> 1)) & 0x5555555555555555ULL;
+            int m = d ? ctz64(d) >> 1 : 32;
+            if (__builtin_expect(m == 32, 0)) m = wave_equal_len(r_end + idx, qp, 32);
+            seed_consider(r_end + idx, m, ref_pred, sp, sl);
+        }
+        // trip 2: the buckets of the steps 0 .. l (hashes from the text) and, should the seed stand and be a close match,
+        // the right diagonal of its gap fill and the first chunk of its forward extension
+        const int tb = I.kb - I.dirbits;
+        const u32 hq = (u32)mix_key((u64)(wql & (u32)lowmask(I.kb)), I.kb);          // (mal <= 15: the mal-mer sits in the low dword)
+        const bool close = iabs(sp - ref_pred) <= P.mrd;
+        const int rre = sp + sl;
+        const int to_scan = rre < r_end ? l : imin(rre - r_end, l), shift = l - to_scan;
+        const int fq = qp + sl, fr = sp + sl;
+        const int nf = imax(0, imin(64, imin(Q.len - fq, R.len - fr)));
+        bool probe = lane <= l;
+        if (JOIN) {
+            const int sh = i & 63;
+            const u64 steps = (bcast64(cw, 0) >> sh) | ((bcast64(cw, 1) << 1) << (63 - sh));      // bit j = step i + j is a candidate
+            probe &= (bool)((steps >> lane) & 1ULL);
+        }
+        uint4 bkv = reinterpret_cast<const uint4*>(I.bk)[probe ? hq >> tb : 0u];
+        SymReq y = sym_request(rre - to_scan + lane, i + shift + lane), z = sym_request(fr + lane, fq + lane);
+        asm volatile("" : "+v"(bkv.x), "+v"(bkv.y), "+v"(bkv.z), "+v"(bkv.w), "+v"(y.wr), "+v"(y.wq), "+v"(z.wr), "+v"(z.wq));
+        const u32 tag = hq & I.tagmask, pmk = (u32)lowmask(I.posbits);
+        const bool m0 = (bkv.x >> I.posbits) == tag, m1 = (bkv.y >> I.posbits) == tag, m2 = (bkv.z >> I.posbits) == tag,
+                   m3 = (bkv.w >> I.posbits) == tag;
+        const int cnt = (int)m0 + (int)m1 + (int)m2 + (int)m3;
+        const bool ovf = bkv.w == BK_OVERFLOW;
+        const u32 en = m0 ? bkv.x : m1 ? bkv.y : m2 ? bkv.z : bkv.w;
+        const int apos = (int)(en & pmk);
+        const u64 simple = wballot(probe & !ovf & (cnt == 1));
+        u64 amask = wballot(probe & (ovf | (cnt > 0)));
+        const int sp0 = sp, sl0 = sl;
+        for (int it = 0; it < 66 && amask; ++it) {
+            const int la = ctz64(amask);
+            amask &= amask - 1;
+            int ap = 0, al = 0;
+            if ((simple >> la) & 1ULL) {
+                // the mal-mer occurs once in the reference: its match length from the registers where the position is one
+                // of the window's (the continuation of the stretch), else by the wave
+                const int pos = __builtin_amdgcn_readlane(apos, la);
+                const int off = pos - r_end;
+                int m;
+                if (la == l && pos == sp0) m = sl0;
+                else if (off >= 0 && off < 128) {
+                    const u64 wr = off < 64 ? bcast64(((u64)w0h << 32) | w0l, off) : bcast64(((u64)w1h << 32) | w1l, off - 64);
+                    const u64 wl = bcast64(((u64)wqh << 32) | wql, la);
+                    const u64 x = wl ^ wr, d = (x | (x >> 1)) & 0x5555555555555555ULL;
+                    m = d ? ctz64(d) >> 1 : 32;
+                    if (m == 32) m = wave_equal_len(pos, i + la, 32);
+                } else m = wave_equal_len(pos, i + la, 0);
+                if (m >= P.mal) { ap = pos; al = m; }
+            } else anchor_by_wave((u32)__builtin_amdgcn_readlane((int)hq, la), i + la, ap, al);
+            if (la < l) {                       // a step before the seed's: its anchor, if it has one, is the event
+                if (ap != 0 && al >= P.msl) { adv = la; bpos = ap; blen = al; LZ_PS(11); return 1; }
+            } else arbitrate(P, R.len, l, ap, al, sp, sl);
+        }
+        adv = l; bpos = sp; blen = sl;
+        LZ_PS(12); LZ_PSN(14, l);
+        if (close && sp == sp0 && sl == sl0) {
+            LZ_PS(13);
+            ev.masks = true;
+            ev.to_scan = to_scan; ev.nf = nf;
+            ev.Lm = wballot((lane < to_scan) & (((wql ^ w0l) & 3u) != 0));
+            ev.Rm = wballot((lane < to_scan) & sym_differs(y));
+            ev.Bf = wballot((lane < nf) & sym_differs(z));
+        }
+        return 1;
     }
     __device__ __forceinline__ ExtMasks ext_scan(u64 prevB, u64 B, int n) const
     {
@@ -1904,7 +2495,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
     iv.bk = a.bk ? a.bk + slot * a.bk_stride : nullptr;
     iv.tw = a.tw ? a.tw + slot * a.tw_stride : nullptr;
     const bool nfree = NFREE ? true : !(a.G.hasN[r] | a.G.hasN[q]);
-#ifdef LZANI_STAMPS
+#if defined(LZANI_STAMPS) || defined(LZANI_PATH_STATS)
     constexpr int CHAIN = (FAST && BK && !ALN && !LFLT) ? chain_of(DEFP, NFREE) : 0;     // (diagnostic build: the block kernel's stamps do not stay scalar around the hand-written loop)
 #else
     constexpr int CHAIN = (FAST && BK && !ALN) ? chain_of(DEFP, NFREE) : 0;
@@ -1950,6 +2541,10 @@ __device__ __forceinline__ void pair_body(const PairArgs& a, u32 lo, u32 j, int 
         atomicAdd(&g_phase_time[2], lane == 0 ? w.pt_refill : 0ULL);
         atomicAdd(&g_phase_time[3], lane == 0 ? 1ULL : 0ULL);
     }
+#endif
+#ifdef LZANI_PATH_STATS
+    for (int k = 0; k < 24; ++k) atomicAdd(&g_path_stats[k], lane == 0 ? (unsigned long long)w.ps[k] : 0ULL);
+    for (int k = 0; k < 12; ++k) atomicAdd(&g_path_stats[24 + k], lane == 0 ? (unsigned long long)w.pw[k] : 0ULL);
 #endif
 #ifdef LZANI_CHAIN_STATS
     for (int k = 0; k < 8; ++k) atomicAdd(&g_chain_stats[k], lane == 0 ? (unsigned long long)w.st[k] : 0ULL);

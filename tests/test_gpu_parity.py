@@ -567,6 +567,56 @@ def test_bacterial_geometry_5mbp(monkeypatch):
     assert got[0, 1, 0] > 4_500_000 and got[3, 4, 0] > 4_000_000 and got[0, 3, 0] < 1_000_000
 
 
+def test_long_genomes_presence_matrix_natural_trigger():
+    """BASELINE configs[3] at its own geometry with enough genomes that the candidate-bitmap form is chosen BY ITSELF (dense
+    rows, >= 32 of them: no LZANI_PM_MIN_ROWS): 33 genomes of 4.6-5.2 Mbp in four families, --mal 15 --msl 9 --reg 60 --
+    2^30 matrix rows of 16 bytes, 690 KB of bitmap per pair, the null chain of the long-genome parameter set.  48 seeded
+    pairs (half of them related) against the reference's parser, size-independent properties on all 1,056."""
+    st = SG.Stream(3303)
+    prm = dict(mal=15, msl=9, reg=60)
+    seqs, fam = [], []
+    for f, members in enumerate((9, 9, 8, 7)):
+        anc = (st.u64(st.randint(4_600_000, 5_200_000)) % np.uint64(4)).astype(np.uint8)
+        seqs.append(anc); fam.append(f)
+        for _ in range(members - 1):
+            seqs.append(SG.mutate(anc, 0.005 + 0.075 * st.one(), st)); fam.append(f)
+    n = len(seqs)
+    assert n == 33
+    eng = L.Engine(prm)
+    eng.set_genomes(seqs)
+    got = eng.all2all()
+    lay = eng.layout()
+    tm = eng.timing()
+    eng.close()
+    assert lay["bitmap_launches"] >= 1 and lay["bitmap_launches"] == lay["batches_last_run"] and lay["join_lists"] == 1, lay
+    print(f"33 x 5 Mbp: pair kernel {tm['pairs_ms']:.0f} ms, candidate stage {tm['cand_ms']:.0f} ms, index {tm['index_ms']:.0f} ms, k-mer words {tm['kmers_ms']:.0f} ms")
+    lens = np.array([len(s) for s in seqs])
+    fam = np.array(fam)
+    for r in range(n):
+        for q in range(n):
+            mat, lit, comp = (int(x) for x in got[r, q])
+            if r == q:
+                assert (mat, lit, comp) == (0, 0, 0)
+            elif fam[r] == fam[q]:
+                assert mat > 0.6 * min(lens[r], lens[q]) and comp >= 1 and mat + lit <= lens[q], (r, q, mat, lit, comp)
+            else:
+                assert mat + lit < 0.02 * lens[q], (r, q, mat, lit, comp)
+    pairs = []
+    while len(pairs) < 48:
+        r, q = st.randint(0, n - 1), st.randint(0, n - 1)
+        if r != q and (fam[r] == fam[q]) == (len(pairs) % 2 == 0):
+            pairs.append((r, q))
+    rr = np.array([p[0] for p in pairs], np.uint32)
+    qq = np.array([p[1] for p in pairs], np.uint32)
+    off = np.arange(len(pairs) + 1, dtype=np.uint64)
+    if O.lib_ref() is not None:
+        want = O.ref_rows(seqs, rr, off, qq, prm, threads=16)
+    else:
+        want = np.array([O.oracle_pair(seqs[r], seqs[q], prm) for r, q in pairs], dtype=np.int32)
+    for k, (r, q) in enumerate(pairs):
+        assert tuple(got[r, q]) == tuple(int(x) for x in want[k]), (r, q, got[r, q], want[k])
+
+
 def test_join_form_of_candidate_detection(monkeypatch):
     """Long genomes find their candidates by a join of the query's sorted k-mer list with the reference's tag words
     instead of one probe per query position.  LZANI_JOIN_MIN_BYTES=1 turns the join on at every size, so the committed
@@ -780,12 +830,14 @@ def test_run_time_compiled_parameter_tuples(monkeypatch, tmp_path):
             q = np.array([[(r + 1) % n, (r + 2) % n, (r + 7) % n] for r in range(n)], dtype=np.uint32).reshape(-1)
             out = eng.run_rows(rr, off, q).reshape(n, 3, 3)
             lay = eng.layout()
-            assert lay["bitmap_launches"] == 0 and lay["rtc_launches"] == 1, (prm, name, lay)
+            # (filtered rows take the anchor queue -- and with it the run-time compiled kernel -- where the index has tag words:
+            # tags of up to 7 bits; mal 12 at this size has 8)
+            assert lay["bitmap_launches"] == 0 and lay["rtc_launches"] == lay["tag_words"], (prm, name, lay)
             for r in range(n):
                 assert np.array_equal(out[r], want[r, [(r + 1) % n, (r + 2) % n, (r + 7) % n]]), (prm, name, "rows", r)
             info = eng.rtc_info()
             eng.close()
-            assert info["folded_ahead_of_time"] == 0 and info["null_chain"] == chain and info["kernels_built"] == 2 and info["kernels_failed"] == 0, info
+            assert info["folded_ahead_of_time"] == 0 and info["null_chain"] == chain and info["kernels_built"] == 1 + lay["tag_words"] and info["kernels_failed"] == 0, info
     # the same tuple again: from the disk cache
     eng = L.Engine(tuples[0])
     eng.set_genomes(seqs)

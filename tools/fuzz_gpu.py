@@ -48,7 +48,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "rtc":
                 chain_tuples += info["null_chain"]
             build_ms += info["build_ms"]
             ok = np.array_equal(got, want) and all(np.array_equal(out[r], want[r, qs[r]]) for r in range(n))
-            if not ok or la["rtc_launches"] != la["bitmap_launches"] or la["bitmap_launches"] != 1 or lb["rtc_launches"] != 1:
+            if not ok or la["rtc_launches"] != la["bitmap_launches"] or la["bitmap_launches"] != 1 or lb["rtc_launches"] != lb["tag_words"]:
                 bad += 1
                 print("RTC MISMATCH" if not ok else "NOT THE RUN-TIME KERNEL", prm, [len(x) for x in seqs], la, lb, info, flush=True)
             cases += 1
