@@ -644,16 +644,8 @@ template <class W> struct wave_has_null_chain<W, std::void_t<decltype(W::NULL_CH
 template <class W, class = void> struct wave_has_mism3 : std::false_type {};
 template <class W> struct wave_has_mism3<W, std::void_t<decltype(W::HAS_MISM3)>> : std::bool_constant<W::HAS_MISM3> {};
 
-// a policy may find the event behind a match in a related stretch straight from the packed texts, with the masks of the close
-// match's gap fill and first forward chunk in hand (DevWave::stretch_event)
-template <class W, class = void> struct wave_has_stretch : std::false_type {};
-template <class W> struct wave_has_stretch<W, std::void_t<decltype(W::HAS_STRETCH)>> : std::bool_constant<W::HAS_STRETCH> {};
 template <class W, class = void> struct wave_has_stretch_chain : std::false_type {};
 template <class W> struct wave_has_stretch_chain<W, std::void_t<decltype(W::HAS_STRETCH_CHAIN)>> : std::bool_constant<W::HAS_STRETCH_CHAIN> {};
-struct NoStretch { bool masks; u64 Lm, Rm, Bf; int to_scan, nf; };
-template <class W, bool HAS> struct stretch_type { typedef NoStretch type; };
-template <class W> struct stretch_type<W, true> { typedef typename W::Stretch type; };
-
 template <class W, bool ALN = false>
 struct PairMachine {
     W& w;
@@ -770,20 +762,14 @@ struct PairMachine {
     // compare_ranges_both_ways folded (parser.cpp:251-374); len = literal run <= 64
     // fq / fr / nf / Bf: the first chunk of the forward extension behind the close match, fetched with the gap's two
     // diagonals where the policy can (haveF says whether it was)
-    // pre: the three masks already in hand (the policy's stretch_event fetched them with the event)
-    template <class PRE = NoStretch>
-    LZ_HD void gap_fill(int ds, int r_left, int r_right_end, int len, int fq = 0, int fr = 0, int nf = 0, u64* Bf = nullptr, bool* haveF = nullptr,
-                        const PRE* pre = nullptr)
+    LZ_HD void gap_fill(int ds, int r_left, int r_right_end, int len, int fq = 0, int fr = 0, int nf = 0, u64* Bf = nullptr, bool* haveF = nullptr)
     {
-        if (pre && pre->masks && Bf) { *Bf = pre->Bf; *haveF = true; }
         if (len <= 0) return;
         int to_scan = (r_right_end < r_left) ? len : imin(r_right_end - r_left, len);
         int shift = len - to_scan;
         u64 F = 0;
         if (to_scan > 0) {
             u64 Lm, Rm;
-            if (pre && pre->masks) { Lm = pre->Lm; Rm = pre->Rm; }
-            else
             if constexpr (wave_has_mism3<W>::value && !ALN) {
                 if (Bf) { w.mism3(ds, r_left, to_scan, ds + shift, r_right_end - to_scan, to_scan, fq, fr, nf, Lm, Rm, *Bf); *haveF = true; }
                 else w.mism2(ds, r_left, 1, to_scan, ds + shift, r_right_end - to_scan, 1, to_scan, Lm, Rm);
@@ -844,9 +830,6 @@ struct PairMachine {
                 }
             }
             w.stamp(4);
-            typename stretch_type<W, wave_has_stretch<W>::value>::type pre;
-            pre.masks = false;
-            bool stretched = false;
             int sc_kind = 0;
             bool sc_hit = false;
             if constexpr (wave_has_stretch_chain<W>::value && !ALN) {
@@ -873,11 +856,7 @@ struct PairMachine {
                     }
                 }
             }
-            if constexpr (wave_has_stretch<W>::value && !ALN) {
-                // behind a match, beyond everything the queue has detected (an extension moved: a related stretch)
-                if (!sc_hit && sc_kind != 3 && in_hand == 0 && trk && lit == 0 && !w.chain_covers(i)) stretched = w.stretch_event(i, iend - i, r_end, adv, bpos, blen, pre) != 0;
-            }
-            const bool hit = sc_hit || stretched || in_hand >= 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);   // (2, 4: the chain found the event)
+            const bool hit = sc_hit || in_hand >= 2 || w.find_event(i, iend - i, trk, r_end, lit, adv, bpos, blen);   // (2, 4: the chain found the event)
 #if defined(LZANI_CHAIN_STATS) && defined(__HIP_DEVICE_COMPILE__)
             w.st[6] += hit && in_hand != 2;
 #endif
@@ -903,7 +882,7 @@ struct PairMachine {
                 // close match: fill the gap, then the match itself (parser.cpp:630-635; quirk Q2)
                 if constexpr (wave_has_mism3<W>::value && !ALN) {
                     fq = i + blen; fr = bpos + blen;
-                    gap_fill(i - lit, r_end, bpos + blen, lit, fq, fr, imax(0, imin(64, imin(D - fq, T - fr))), &Bf, &haveF, &pre);
+                    gap_fill(i - lit, r_end, bpos + blen, lit, fq, fr, imax(0, imin(64, imin(D - fq, T - fr))), &Bf, &haveF);
                 } else gap_fill(i - lit, r_end, bpos + blen, lit);
                 match_run(i, bpos, blen);
             } else {

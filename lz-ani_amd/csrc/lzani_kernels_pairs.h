@@ -134,6 +134,8 @@ struct DevWave {
     // of the pair's bitmap to read: the next find_event call only refills (from i, if queued candidates are left)
     bool refill_only = false;
     int restart_at = -1;         // the last i a refill restarted the detection at (no second restart at the same place)
+    // the stretch chain has done the tracking round of the next find_event call and found no seed in it
+    bool round_no_seed = false;
     // the tracking round null_chain has done for the next find_event call (CHAIN)
     bool pre_round = false;
     u64 pre_seed = 0;
@@ -1591,7 +1593,13 @@ struct DevWave {
     // before and after every event).  Stops with nothing half-done at the first event that is not this cycle; returns
     // the number of events it committed.  ~125 vector + ~100 scalar instructions per event against ~330 + ~390 by the
     // compiler's path (profiles/r4_related_*: the related kernel is bound by instruction issue, the scalar unit first).
-    static constexpr bool HAS_STRETCH_CHAIN = CHAIN != 0 && !JOIN && (ChainP<CHAIN>::MQD <= ChainP<CHAIN>::MRD);
+    // (in the kernels where related pairs are what the time goes into: filtered rows -- the probe form -- and the bitmap forms of
+    // the long-genome parameter sets; the dense viral kernel, 999 unrelated pairs in 1,000, stays lean: the loop costs it 2.5 %)
+#ifndef LZANI_STRETCH_DENSE
+#define LZANI_STRETCH_DENSE 0
+#endif
+    static constexpr bool HAS_STRETCH_CHAIN = CHAIN != 0 && (ChainP<CHAIN>::MQD <= ChainP<CHAIN>::MRD) &&
+                                              (!JOIN || ChainP<CHAIN>::MAL >= 13 || LZANI_STRETCH_DENSE);
     // kind: 0 = nothing in hand; 1 = the last event's gap and match are committed, its forward extension is not: Bf = the
     // mismatches of its first chunk (no break inside it); 2 = a step before the first seed step has an anchor candidate:
     // step (adv) and its mixed hash (hq); 3 = the tracking steps of i hold no seed (their anchors decide: find_event)
@@ -1615,6 +1623,9 @@ struct DevWave {
         int ncm, t0, t1, t2, kb, kc, gap, rec, cls, fok, blen, anc, aent;
         u64 m, seed, m2, pmk;
         u32 rk0, rk1, qk, hq, a0, a1, aq, t, bq, w1, dumv;
+        [[maybe_unused]] u64 cwa, cwb;                     // bitmap form: two words of the pair's candidate bitmap
+        [[maybe_unused]] u32 e0, e1, e2, e3, tagl;         //              the seed step's bucket, its tag
+        [[maybe_unused]] const unsigned long long* const cbp = JOIN ? reinterpret_cast<const unsigned long long*>(uniform_ptr(reinterpret_cast<const u32*>(cand_bits))) : nullptr;
 #if defined(LZANI_STAMPS) || defined(LZANI_PATH_STATS)
         i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end);
         cl = __builtin_amdgcn_readfirstlane(cl); clit = __builtin_amdgcn_readfirstlane(clit);
@@ -1630,7 +1641,130 @@ struct DevWave {
 #define LZ_SC_WHY(n)
 #define LZ_SC_WHY_OPERAND
 #endif
-#define LZ_SC_ASM(WORD) \
+        // ---- the two forms of "which steps up to the seed's have an anchor candidate" ----
+        // probe form: the steps' tag words (a zero byte in w ^ rep4(0x80 | tag) = a slot of the bucket carrying the step's tag)
+#define LZ_SC_P_CANDLOAD
+#define LZ_SC_P_TWADDR \
+            "v_lshrrev_b32_e32 %[bq], %[TB], %[hq]\n\t"     /* the step's bucket */ \
+            "v_cmp_ge_u32_e32 vcc, %[t0], %[lane]\n\t"      /* the steps up to the seed's */
+#define LZ_SC_P_TWADDR2 \
+            "v_lshlrev_b32_e32 %[bq], 2, %[bq]\n\t" \
+            "v_cndmask_b32_e32 %[bq], 0, %[bq], vcc\n\t"
+#define LZ_SC_P_TWLOAD \
+            "s_mov_b64 %[pmk], vcc\n\t" \
+            "s_nop 0\n\t" \
+            "global_load_dword %[bq], %[bq], %[twp]\n\t"
+#define LZ_SC_P_VWAIT "s_waitcnt vmcnt(0)\n\t"
+#define LZ_SC_P_TWSWAR \
+            "v_and_b32_e32 %[a0], %[TAGM], %[hq]\n\t" \
+            "v_or_b32_e32 %[a0], 0x80, %[a0]\n\t" \
+            "v_perm_b32 %[a0], %[a0], %[a0], %[zero]\n\t" \
+            "v_xor_b32_e32 %[a0], %[a0], %[bq]\n\t"         /* x */ \
+            "v_subrev_u32_e32 %[a1], 0x01010101, %[a0]\n\t" \
+            "v_not_b32_e32 %[a0], %[a0]\n\t" \
+            "v_and_b32_e32 %[a1], %[a1], %[a0]\n\t" \
+            "v_and_b32_e32 %[a1], 0x80808080, %[a1]\n\t"    /* z: its lowest flag is exact */
+#define LZ_SC_P_CANDMASK \
+            "v_cmp_ne_u32_e32 vcc, 0, %[a1]\n\t" \
+            "s_mov_b64 %[m2], vcc\n\t" \
+            "v_cmp_eq_u32_e32 vcc, 0x808080ff, %[bq]\n\t"   /* an overflowing bucket (TW_OVERFLOW) */ \
+            "s_or_b64 %[m2], %[m2], vcc\n\t" \
+            "s_and_b64 %[m2], %[m2], %[pmk]\n\t"            /* the steps <= l with an anchor candidate */
+#define LZ_SC_P_ANCENTRY \
+            /* at the seed's own step: the entry behind the tag must be the seed itself */ \
+            "v_readlane_b32 %[kc], %[a1], %[t0]\n\t"        /* z */ \
+            "v_readlane_b32 %[t1], %[bq], %[t0]\n\t"        /* w */ \
+            "v_readlane_b32 %[t2], %[hq], %[t0]\n\t" \
+            "s_cmp_eq_u32 %[t1], 0x808080ff\n\t" \
+            LZ_SC_WHY(7) "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            "s_sub_u32 %[t1], %[kc], 1\n\t" \
+            "s_and_b32 %[t1], %[t1], %[kc]\n\t" \
+            "s_cmp_lg_u32 %[t1], 0\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t"                 /* the tag in two slots */ \
+            "s_ff1_i32_b32 %[kc], %[kc]\n\t" \
+            "s_lshr_b32 %[kc], %[kc], 3\n\t"                /* the slot */ \
+            "s_lshr_b32 %[t2], %[t2], %[TB]\n\t" \
+            "s_lshl_b32 %[t2], %[t2], 2\n\t" \
+            "s_add_u32 %[t2], %[t2], %[kc]\n\t" \
+            "s_lshl_b32 %[t2], %[t2], 2\n\t" \
+            "s_load_dword %[aent], %[bkp], %[t2]\n\t" \
+            "s_mov_b32 %[anc], 1\n"
+#define LZ_SC_P_ANCCHECK \
+            "s_bfm_b32 %[anc], %[PB], 0\n\t" \
+            "s_and_b32 %[aent], %[aent], %[anc]\n\t" \
+            LZ_SC_WHY(8) "s_cmp_lg_u32 %[aent], %[rec]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n"
+#define LZ_SC_P_XOUT
+#define LZ_SC_P_XIN , [twp] "s"(twp)
+        // bitmap form: two words of the pair's candidate bitmap (scalar loads: issued behind the round's LDS operations, which
+        // share the counter), the four entries of the seed step's bucket by four more
+#define LZ_SC_J_CANDLOAD \
+            "s_lshr_b32 %[t1], %[i], 6\n\t" \
+            "s_lshl_b32 %[t1], %[t1], 3\n\t" \
+            "s_add_u32 %[t2], %[t1], 8\n\t" \
+            "s_waitcnt lgkmcnt(0)\n\t" \
+            "s_load_dwordx2 %[cwa], %[cbp], %[t1]\n\t" \
+            "s_load_dwordx2 %[cwb], %[cbp], %[t2]\n\t"
+#define LZ_SC_J_TWADDR
+#define LZ_SC_J_TWADDR2
+#define LZ_SC_J_TWLOAD
+#define LZ_SC_J_VWAIT "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+#define LZ_SC_J_TWSWAR
+#define LZ_SC_J_CANDMASK \
+            "s_and_b32 %[t1], %[i], 63\n\t" \
+            "s_lshr_b64 %[m2], %[cwa], %[t1]\n\t" \
+            "s_sub_i32 %[t1], 63, %[t1]\n\t" \
+            "s_lshl_b64 %[pmk], %[cwb], 1\n\t" \
+            "s_lshl_b64 %[pmk], %[pmk], %[t1]\n\t" \
+            "s_or_b64 %[m2], %[m2], %[pmk]\n\t"             /* bit j = step i + j has an anchor candidate */ \
+            "s_add_i32 %[t1], %[t0], 1\n\t" \
+            "s_bfm_b64 %[pmk], %[t1], 0\n\t" \
+            "s_and_b64 %[m2], %[m2], %[pmk]\n\t"            /* the steps <= l */
+#define LZ_SC_J_ANCENTRY \
+            "v_readlane_b32 %[t2], %[hq], %[t0]\n\t" \
+            "s_lshr_b32 %[t1], %[t2], %[TB]\n\t" \
+            "s_lshl_b32 %[t1], %[t1], 4\n\t" \
+            "s_and_b32 %[tagl], %[t2], %[TAGM]\n\t"         /* the step's tag */ \
+            "s_load_dword %[e0], %[bkp], %[t1]\n\t" \
+            "s_add_u32 %[t2], %[t1], 4\n\t" \
+            "s_load_dword %[e1], %[bkp], %[t2]\n\t" \
+            "s_add_u32 %[anc], %[t1], 8\n\t" \
+            "s_load_dword %[e2], %[bkp], %[anc]\n\t" \
+            "s_add_u32 %[aent], %[t1], 12\n\t" \
+            "s_load_dword %[e3], %[bkp], %[aent]\n\t" \
+            "s_mov_b32 %[anc], 1\n"
+#define LZ_SC_J_ANCCHECK \
+            /* exactly one of the bucket's four entries carries the tag, no overflow, and it sits at the seed's position */ \
+            "s_cmp_eq_u32 %[e3], 0xfffffffe\n\t" \
+            LZ_SC_WHY(7) "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            "s_mov_b32 %[anc], 0\n\t" \
+            "s_mov_b32 %[aent], 0\n\t" \
+            "s_lshr_b32 %[t2], %[e0], %[PB]\n\t" \
+            "s_cmp_eq_u32 %[t2], %[tagl]\n\t" \
+            "s_cselect_b32 %[aent], %[e0], %[aent]\n\t" \
+            "s_addc_u32 %[anc], %[anc], 0\n\t" \
+            "s_lshr_b32 %[t2], %[e1], %[PB]\n\t" \
+            "s_cmp_eq_u32 %[t2], %[tagl]\n\t" \
+            "s_cselect_b32 %[aent], %[e1], %[aent]\n\t" \
+            "s_addc_u32 %[anc], %[anc], 0\n\t" \
+            "s_lshr_b32 %[t2], %[e2], %[PB]\n\t" \
+            "s_cmp_eq_u32 %[t2], %[tagl]\n\t" \
+            "s_cselect_b32 %[aent], %[e2], %[aent]\n\t" \
+            "s_addc_u32 %[anc], %[anc], 0\n\t" \
+            "s_lshr_b32 %[t2], %[e3], %[PB]\n\t" \
+            "s_cmp_eq_u32 %[t2], %[tagl]\n\t" \
+            "s_cselect_b32 %[aent], %[e3], %[aent]\n\t" \
+            "s_addc_u32 %[anc], %[anc], 0\n\t" \
+            "s_cmp_lg_u32 %[anc], 1\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n\t" \
+            "s_bfm_b32 %[anc], %[PB], 0\n\t" \
+            "s_and_b32 %[aent], %[aent], %[anc]\n\t" \
+            LZ_SC_WHY(8) "s_cmp_lg_u32 %[aent], %[rec]\n\t" \
+            "s_cbranch_scc1 Lsc_end_%=\n"
+#define LZ_SC_J_XOUT , [cwa] "=&s"(cwa), [cwb] "=&s"(cwb), [e0] "=&s"(e0), [e1] "=&s"(e1), [e2] "=&s"(e2), [e3] "=&s"(e3), [tagl] "=&s"(tagl)
+#define LZ_SC_J_XIN , [cbp] "s"(cbp)
+#define LZ_SC_CAT(F, X) LZ_SC_##F##_##X
+#define LZ_SC_ASM(WORD, F) \
         asm volatile( \
             "s_mov_b32 %[ncm], 0\n\t" "s_mov_b32 %[kind], 0\n\t" LZ_SC_WHY(10) \
             "v_add_u32_e32 %[w1], 64, %[lane]\n\t" \
@@ -1652,6 +1786,7 @@ struct DevWave {
             LZ_NC_FIX \
             LZ_SC_WHY(2) "s_cmp_eq_u64 %[m], 0\n\t" \
             "s_cbranch_scc1 Lsc_noseed_%=\n\t" \
+            LZ_SC_CAT(F, CANDLOAD) \
             "s_ff1_i32_b64 %[t0], %[m]\n"                   /* l: the first step with a seed candidate */ \
             "Lsc_sdl_%=:\n\t" \
             "v_readlane_b32 %[t1], %[qk], %[t0]\n\t"        /* the step's msl-mer */ \
@@ -1703,45 +1838,29 @@ struct DevWave {
             "v_add_u32_e32 %[a1], %[t2], %[lane]\n\t" \
             "v_lshrrev_b32_e32 %[aq], 4, %[a0]\n\t" \
             "v_lshrrev_b32_e32 %[t], 4, %[a1]\n\t" \
-            "v_lshrrev_b32_e32 %[bq], %[TB], %[hq]\n\t"     /* the step's bucket */ \
-            "v_cmp_ge_u32_e32 vcc, %[t0], %[lane]\n\t"      /* the steps up to the seed's */ \
+            LZ_SC_CAT(F, TWADDR) \
             "v_lshlrev_b32_e32 %[aq], 2, %[aq]\n\t" \
             "v_lshlrev_b32_e32 %[t], 2, %[t]\n\t" \
-            "v_lshlrev_b32_e32 %[bq], 2, %[bq]\n\t" \
-            "v_cndmask_b32_e32 %[bq], 0, %[bq], vcc\n\t" \
+            LZ_SC_CAT(F, TWADDR2) \
             "global_load_dword %[aq], %[aq], %[rt2]\n\t" \
             "global_load_dword %[t], %[t], %[qt2]\n\t" \
-            "s_mov_b64 %[pmk], vcc\n\t" \
-            "s_nop 0\n\t" \
-            "global_load_dword %[bq], %[bq], %[twp]\n\t" \
+            LZ_SC_CAT(F, TWLOAD) \
             "v_and_b32_e32 %[a0], 15, %[a0]\n\t" \
             "v_and_b32_e32 %[a1], 15, %[a1]\n\t" \
             "v_lshlrev_b32_e32 %[a0], 1, %[a0]\n\t" \
             "v_lshlrev_b32_e32 %[a1], 1, %[a1]\n\t" \
-            "s_waitcnt vmcnt(0)\n\t" \
+            LZ_SC_CAT(F, VWAIT) \
             "v_lshrrev_b32_e32 %[aq], %[a0], %[aq]\n\t" \
             "v_lshrrev_b32_e32 %[t], %[a1], %[t]\n\t" \
             "v_xor_b32_e32 %[aq], %[aq], %[t]\n\t" \
             "v_and_b32_e32 %[aq], 3, %[aq]\n\t" \
             "v_cmp_ne_u32_e64 %[m], 0, %[aq]\n\t" \
-            /* anchor candidates: a zero byte in w ^ rep4(0x80 | tag) = a slot of the bucket carrying the step's tag */ \
-            "v_and_b32_e32 %[a0], %[TAGM], %[hq]\n\t" \
-            "v_or_b32_e32 %[a0], 0x80, %[a0]\n\t" \
-            "v_perm_b32 %[a0], %[a0], %[a0], %[zero]\n\t" \
-            "v_xor_b32_e32 %[a0], %[a0], %[bq]\n\t"         /* x */ \
-            "v_subrev_u32_e32 %[a1], 0x01010101, %[a0]\n\t" \
-            "v_not_b32_e32 %[a0], %[a0]\n\t" \
-            "v_and_b32_e32 %[a1], %[a1], %[a0]\n\t" \
-            "v_and_b32_e32 %[a1], 0x80808080, %[a1]\n\t"    /* z: its lowest flag is exact */ \
+            LZ_SC_CAT(F, TWSWAR) \
             "s_cmp_eq_u64 %[m], 0\n\t" \
             LZ_SC_WHY(5) "s_cbranch_scc1 Lsc_end_%=\n\t"                 /* 64 more symbols match: the general path measures on */ \
             "s_ff1_i32_b64 %[blen], %[m]\n\t" \
             "s_add_i32 %[blen], %[blen], %[MSL]\n\t" \
-            "v_cmp_ne_u32_e32 vcc, 0, %[a1]\n\t" \
-            "s_mov_b64 %[m2], vcc\n\t" \
-            "v_cmp_eq_u32_e32 vcc, 0x808080ff, %[bq]\n\t"   /* an overflowing bucket (TW_OVERFLOW) */ \
-            "s_or_b64 %[m2], %[m2], vcc\n\t" \
-            "s_and_b64 %[m2], %[m2], %[pmk]\n\t"            /* the steps <= l with an anchor candidate */ \
+            LZ_SC_CAT(F, CANDMASK) \
             "s_bfm_b64 %[seed], %[t0], 0\n\t" \
             "s_and_b64 %[seed], %[seed], %[m2]\n\t" \
             "s_cmp_lg_u64 %[seed], 0\n\t" \
@@ -1749,24 +1868,7 @@ struct DevWave {
             "s_mov_b32 %[anc], 0\n\t" \
             "s_cmp_eq_u64 %[m2], 0\n\t" \
             "s_cbranch_scc1 Lsc_noanc_%=\n\t" \
-            /* at the seed's own step: the entry behind the tag must be the seed itself */ \
-            "v_readlane_b32 %[kc], %[a1], %[t0]\n\t"        /* z */ \
-            "v_readlane_b32 %[t1], %[bq], %[t0]\n\t"        /* w */ \
-            "v_readlane_b32 %[t2], %[hq], %[t0]\n\t" \
-            "s_cmp_eq_u32 %[t1], 0x808080ff\n\t" \
-            "s_cbranch_scc1 Lsc_end_%=\n\t" \
-            "s_sub_u32 %[t1], %[kc], 1\n\t" \
-            "s_and_b32 %[t1], %[t1], %[kc]\n\t" \
-            "s_cmp_lg_u32 %[t1], 0\n\t" \
-            LZ_SC_WHY(7) "s_cbranch_scc1 Lsc_end_%=\n\t"                 /* the tag in two slots */ \
-            "s_ff1_i32_b32 %[kc], %[kc]\n\t" \
-            "s_lshr_b32 %[kc], %[kc], 3\n\t"                /* the slot */ \
-            "s_lshr_b32 %[t2], %[t2], %[TB]\n\t" \
-            "s_lshl_b32 %[t2], %[t2], 2\n\t" \
-            "s_add_u32 %[t2], %[t2], %[kc]\n\t" \
-            "s_lshl_b32 %[t2], %[t2], 2\n\t" \
-            "s_load_dword %[aent], %[bkp], %[t2]\n\t" \
-            "s_mov_b32 %[anc], 1\n" \
+            LZ_SC_CAT(F, ANCENTRY) \
             "Lsc_noanc_%=:\n\t" \
             /* The close match (as in the null chain): t0 = l, rec / cls = the seed in the reference / query, t1 = fq, fok = fr */ \
             "s_add_i32 %[t1], %[cls], %[blen]\n\t" \
@@ -1822,10 +1924,7 @@ struct DevWave {
             /* the anchor at the seed's step, if there is one, must sit at the seed's position */ \
             "s_cmp_eq_u32 %[anc], 0\n\t" \
             "s_cbranch_scc1 Lsc_anok_%=\n\t" \
-            "s_bfm_b32 %[anc], %[PB], 0\n\t" \
-            "s_and_b32 %[aent], %[aent], %[anc]\n\t" \
-            LZ_SC_WHY(8) "s_cmp_lg_u32 %[aent], %[rec]\n\t" \
-            "s_cbranch_scc1 Lsc_end_%=\n" \
+            LZ_SC_CAT(F, ANCCHECK) \
             "Lsc_anok_%=:\n\t" \
             /* left diagonal -> m = its matches */ \
             "v_add_u32_e32 %[t], %[rend], %[lane]\n\t" \
@@ -1973,20 +2072,27 @@ struct DevWave {
               [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [kb] "=&s"(kb), [kc] "=&s"(kc), [gap] "=&s"(gap), [rec] "=&s"(rec), [cls] "=&s"(cls), \
               [fok] "=&s"(fok), [blen] "=&s"(blen), [anc] "=&s"(anc), [aent] "=&s"(aent), [kind] "=&s"(kind), [m] "=&s"(m), [seed] "=&s"(seed), [m2] "=&s"(m2), [pmk] "=&s"(pmk), \
               [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [hq] "=&v"(hq), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), \
-              [w1] "=&v"(w1), [dumv] "=&v"(dumv) \
-            : [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [qkl] "s"(qkl), [rt2] "s"(rt2), [qt2] "s"(qt2), [twp] "s"(twp), [bkp] "s"(bkp), \
-              [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS), [TB] "s"(tbits), [PB] "s"(pbits), [TAGM] "s"(tagm), \
+              [w1] "=&v"(w1), [dumv] "=&v"(dumv) LZ_SC_CAT(F, XOUT) \
+            : [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [qkl] "s"(qkl), [rt2] "s"(rt2), [qt2] "s"(qt2), [bkp] "s"(bkp), \
+              [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS), [TB] "s"(tbits), [PB] "s"(pbits), [TAGM] "s"(tagm) LZ_SC_CAT(F, XIN), \
               [lane] "v"(lane), [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one), \
               [MRD] "n"(MRD), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64), [MSL] "n"(MSL), [MSL64] "n"(MSL + 64), \
               [C41M] "n"(3 * MRD + 1 - WIN - MSL), [C40M] "n"(MRD - MSL), [CQ64] "n"(MRD + 64), [C2MRD] "n"(2 * MRD), \
               [AW1] "n"(AW - 1), [AW1C] "n"(33 - AW), [AWM] "n"((1 << AW) - 1), [ARM] "n"(((1 << AR) - 1) << (AW - AR)), [AM] "n"(AM), [KS5] "n"(2 * MSL + 5), [KS] "n"(2 * MSL) \
             : "vcc", "scc", "memory");
-        if constexpr (MSL == 9) { LZ_SC_ASM(LZ_NC_WORD9) }
-        else if constexpr (MSL == 8) { LZ_SC_ASM(LZ_NC_WORD8) }
-        else { LZ_SC_ASM(LZ_NC_WORD7) }
+        if constexpr (JOIN) {
+            if constexpr (MSL == 9) { LZ_SC_ASM(LZ_NC_WORD9, J) }
+            else if constexpr (MSL == 8) { LZ_SC_ASM(LZ_NC_WORD8, J) }
+            else { LZ_SC_ASM(LZ_NC_WORD7, J) }
+        } else {
+            if constexpr (MSL == 9) { LZ_SC_ASM(LZ_NC_WORD9, P) }
+            else if constexpr (MSL == 8) { LZ_SC_ASM(LZ_NC_WORD8, P) }
+            else { LZ_SC_ASM(LZ_NC_WORD7, P) }
+        }
 #undef LZ_SC_ASM
         last_src = -1;
         Bf = seed; adv = t0; hqa = (u32)t1;
+        round_no_seed = kind == 3;
         LZ_PSN(23, ncm);
 #ifdef LZANI_PATH_STATS
         pw[why < 12 ? why : 0] += 1;
@@ -2015,6 +2121,8 @@ struct DevWave {
             return find_event_round(i, n, trk, r_end, lit, adv, bpos, blen);
         last_src = -1;
         LZ_PS(0);
+        const bool no_seed = round_no_seed;
+        round_no_seed = false;
         // tracking steps of this call (the machine clears trk once lit > mqd); one lane per tracking step
         const int nt = trk ? imin(imin(n, P.mqd - lit + 1), 64) : 0;
         if (q_head < q_cnt && __builtin_amdgcn_readlane(a_pos, q_head) < i) drop_before(i);
@@ -2077,7 +2185,7 @@ struct DevWave {
             // before its bucket -- one memory round trip less per event of a related stretch)
             const u32 hqv = qkL[(u32)(i + lane)];
             LZ_PS(3);
-            seedmask = track_round(i, nt, r_end, lit, rk0, rk1, qk);
+            seedmask = no_seed ? 0 : track_round(i, nt, r_end, lit, rk0, rk1, qk);
             // The anchors of the steps are probed only as far as they can matter: up to the first step with a seed
             // candidate (a seed is an event: nothing behind it is reached), else the first eight steps, the rest only if
             // none of those hits.  In a related stretch the event is at the first steps, and each probe spared is a
@@ -2198,159 +2306,6 @@ struct DevWave {
         }
         adv = n;
         return false;
-    }
-    // ---- related stretches: the event behind a match straight from the packed texts --------------------------------
-    // Where an approximate extension has carried the scan beyond everything the queue has detected (scan_pos < i: the
-    // pairs a kmer-db filter leaves consist of such stretches), find_event's light round costs a chain of dependent
-    // fetches per event: k-mer words of the steps and of the window, tag words, the bucket, the anchor's text, the seed's
-    // text, then the gap fill's diagonals and the first chunk of the forward extension -- and this kernel, on related
-    // pairs, waits for memory (profiles/r4_related_base_*: 19.8 k L2 misses and 1.9 M wave cycles per pair, 57 % of them
-    // waiting).  Here the event comes out of TWO round trips (N-free pair, the window inside one strand):
-    //   1. every lane fetches 32 symbols of the query from its step on and 32 symbols of the reference from its window
-    //      position(s) on (three dwords each, the same few lines for the whole wave): the msl-mers of steps and window,
-    //      the steps' mal-mer hashes and the first 32 symbols of every seed's match length are then arithmetic on
-    //      registers (no k-mer words: 16 x fewer lines than the u32-per-position arrays);
-    //   2. the buckets of the steps up to the first seed step (read whole: no tag-word probe in front) TOGETHER with what
-    //      the close match will need if the seed stands -- the right diagonal of its gap fill and the first chunk of its
-    //      forward extension; the left diagonal is the step diagonal of trip 1.
-    // The anchors then confirm the speculation (an anchor at an earlier step, or one that wins the arbitration at the
-    // seed's step, makes the event theirs and the masks void).  Semantics: exactly find_event's for the same call
-    // (parser.cpp:533-624); anything outside the simple geometry returns 0 with nothing touched.
-    static constexpr bool HAS_STRETCH = FAST && BK;
-    struct Stretch { bool masks; u64 Lm, Rm, Bf; int to_scan, nf; };
-    __device__ __forceinline__ int stretch_event(int i, int n, int r_end, int& adv, int& bpos, int& blen, Stretch& ev)
-    {
-        ev.masks = false;
-        const int nt = P.mqd + 1, W = P.mqd + P.mrd;
-        const bool strand = (r_end + 160 <= R.L) | ((r_end >= R.rc0) & (r_end + 160 <= R.rc0 + R.L));
-        LZ_PS(8);
-        if (!(R.nfree && Q.nfree) || P.mqd > 63 || W > 128 || n < nt || i + 96 > Q.L || r_end < 0 || !strand) { LZ_PS(9); return 0; }
-        last_src = -1;
-        // trip 1: 32 symbols per lane from step i + lane, window positions r_end + lane and r_end + 64 + lane
-        const u32* const q32 = reinterpret_cast<const u32*>(Q.t2);
-        const u32* const r32 = reinterpret_cast<const u32*>(R.t2);
-        const u32 qa = (u32)(i + lane), ra = (u32)(r_end + lane);
-        u32 q0 = q32[qa >> 4], q1 = q32[(qa >> 4) + 1], q2 = q32[(qa >> 4) + 2];
-        u32 a0 = r32[ra >> 4], a1 = r32[(ra >> 4) + 1], a2 = r32[(ra >> 4) + 2];
-        u32 b0 = r32[(ra >> 4) + 4], b1 = r32[(ra >> 4) + 5], b2 = r32[(ra >> 4) + 6];
-        // (bitmap forms: which of the steps have an anchor candidate at all is in the pair's candidate bitmap -- two words of
-        // it with the same trip; the probe form asks the buckets of all steps up to the seed's)
-        unsigned long long cw = 0;
-        if (JOIN) cw = cand_bits[((u32)i >> 6) + (u32)imin(lane, 1)];
-        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(cw));
-        const u32 sq = (qa & 15u) * 2u, sa = (ra & 15u) * 2u;
-        const u32 wql = __builtin_amdgcn_alignbit(q1, q0, sq), wqh = __builtin_amdgcn_alignbit(q2, q1, sq);
-        const u32 w0l = __builtin_amdgcn_alignbit(a1, a0, sa), w0h = __builtin_amdgcn_alignbit(a2, a1, sa);
-        const u32 w1l = __builtin_amdgcn_alignbit(b1, b0, sa), w1h = __builtin_amdgcn_alignbit(b2, b1, sa);
-        // close seeds: the window's msl-mers into the LDS bitmap, every step tests its own (seed_prefilter)
-        const u32 km = (u32)lowmask(2 * P.msl);
-        const u32 qk = wql & km, rk0 = w0l & km, rk1 = w1l & km;
-        u64 seedmask;
-        {
-            const bool vq = lane < nt, v0 = lane < W, v1 = lane + 64 < W;
-            const u32 hq_ = P.msl <= 7 ? qk : (qk * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
-            const u32 h0 = P.msl <= 7 ? rk0 : (rk0 * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
-            const u32 h1 = P.msl <= 7 ? rk1 : (rk1 * 0x9E3779B1u) >> (32 - SEED_BM_BITS);
-            const u32 scratch = (u32)lane;
-            const u32 x0 = v0 ? h0 >> 5 : scratch, x1 = v1 ? h1 >> 5 : scratch, xq = vq ? hq_ >> 5 : scratch;
-            atomicOr(&bitmap[x0], v0 ? 1u << (h0 & 31) : 0u);
-            atomicOr(&bitmap[x1], v1 ? 1u << (h1 & 31) : 0u);
-            lds_order();
-            const bool hit = vq & ((bitmap[xq] >> (hq_ & 31)) & 1u);
-            lds_order();
-            bitmap[x0] = 0;
-            bitmap[x1] = 0;
-            seedmask = wballot(hit);
-        }
-        // the first step with a real seed candidate (the bitmap holds the whole window, a step may use its first l + mrd positions)
-        int l = -1;
-        u64 d0 = 0, d1 = 0;
-        for (int it = 0; it < 64 && seedmask; ++it) {
-            const int s = ctz64(seedmask);
-            seedmask &= seedmask - 1;
-            const u32 qkl = (u32)__builtin_amdgcn_readlane((int)qk, s);
-            d0 = wballot(rk0 == qkl) & lowmask(s + P.mrd);
-            d1 = wballot(rk1 == qkl) & lowmask(s + P.mrd - 64);
-            if (d0 | d1) { l = s; break; }
-        }
-        if (l < 0) { LZ_PS(10); return 0; }   // no seed within the tracking steps: the anchors of all of them (find_event)
-        // its candidates: the first 32 symbols of each match from the registers
-        const int qp = i + l, ref_pred = r_end + l;
-        const u64 wq = bcast64(((u64)wqh << 32) | wql, l);
-        int sp = 0, sl = 0;
-        for (int it = 0; it < 130 && (d0 | d1); ++it) {
-            int idx;
-            if (d0) { idx = ctz64(d0); d0 &= d0 - 1; }
-            else { idx = 64 + ctz64(d1); d1 &= d1 - 1; }
-            const u64 wr = idx < 64 ? bcast64(((u64)w0h << 32) | w0l, idx) : bcast64(((u64)w1h << 32) | w1l, idx - 64);
-            const u64 x = wq ^ wr, d = (x | (x >> 1)) & 0x5555555555555555ULL;
-            int m = d ? ctz64(d) >> 1 : 32;
-            if (__builtin_expect(m == 32, 0)) m = wave_equal_len(r_end + idx, qp, 32);
-            seed_consider(r_end + idx, m, ref_pred, sp, sl);
-        }
-        // trip 2: the buckets of the steps 0 .. l (hashes from the text) and, should the seed stand and be a close match,
-        // the right diagonal of its gap fill and the first chunk of its forward extension
-        const int tb = I.kb - I.dirbits;
-        const u32 hq = (u32)mix_key((u64)(wql & (u32)lowmask(I.kb)), I.kb);          // (mal <= 15: the mal-mer sits in the low dword)
-        const bool close = iabs(sp - ref_pred) <= P.mrd;
-        const int rre = sp + sl;
-        const int to_scan = rre < r_end ? l : imin(rre - r_end, l), shift = l - to_scan;
-        const int fq = qp + sl, fr = sp + sl;
-        const int nf = imax(0, imin(64, imin(Q.len - fq, R.len - fr)));
-        bool probe = lane <= l;
-        if (JOIN) {
-            const int sh = i & 63;
-            const u64 steps = (bcast64(cw, 0) >> sh) | ((bcast64(cw, 1) << 1) << (63 - sh));      // bit j = step i + j is a candidate
-            probe &= (bool)((steps >> lane) & 1ULL);
-        }
-        uint4 bkv = reinterpret_cast<const uint4*>(I.bk)[probe ? hq >> tb : 0u];
-        SymReq y = sym_request(rre - to_scan + lane, i + shift + lane), z = sym_request(fr + lane, fq + lane);
-        asm volatile("" : "+v"(bkv.x), "+v"(bkv.y), "+v"(bkv.z), "+v"(bkv.w), "+v"(y.wr), "+v"(y.wq), "+v"(z.wr), "+v"(z.wq));
-        const u32 tag = hq & I.tagmask, pmk = (u32)lowmask(I.posbits);
-        const bool m0 = (bkv.x >> I.posbits) == tag, m1 = (bkv.y >> I.posbits) == tag, m2 = (bkv.z >> I.posbits) == tag,
-                   m3 = (bkv.w >> I.posbits) == tag;
-        const int cnt = (int)m0 + (int)m1 + (int)m2 + (int)m3;
-        const bool ovf = bkv.w == BK_OVERFLOW;
-        const u32 en = m0 ? bkv.x : m1 ? bkv.y : m2 ? bkv.z : bkv.w;
-        const int apos = (int)(en & pmk);
-        const u64 simple = wballot(probe & !ovf & (cnt == 1));
-        u64 amask = wballot(probe & (ovf | (cnt > 0)));
-        const int sp0 = sp, sl0 = sl;
-        for (int it = 0; it < 66 && amask; ++it) {
-            const int la = ctz64(amask);
-            amask &= amask - 1;
-            int ap = 0, al = 0;
-            if ((simple >> la) & 1ULL) {
-                // the mal-mer occurs once in the reference: its match length from the registers where the position is one
-                // of the window's (the continuation of the stretch), else by the wave
-                const int pos = __builtin_amdgcn_readlane(apos, la);
-                const int off = pos - r_end;
-                int m;
-                if (la == l && pos == sp0) m = sl0;
-                else if (off >= 0 && off < 128) {
-                    const u64 wr = off < 64 ? bcast64(((u64)w0h << 32) | w0l, off) : bcast64(((u64)w1h << 32) | w1l, off - 64);
-                    const u64 wl = bcast64(((u64)wqh << 32) | wql, la);
-                    const u64 x = wl ^ wr, d = (x | (x >> 1)) & 0x5555555555555555ULL;
-                    m = d ? ctz64(d) >> 1 : 32;
-                    if (m == 32) m = wave_equal_len(pos, i + la, 32);
-                } else m = wave_equal_len(pos, i + la, 0);
-                if (m >= P.mal) { ap = pos; al = m; }
-            } else anchor_by_wave((u32)__builtin_amdgcn_readlane((int)hq, la), i + la, ap, al);
-            if (la < l) {                       // a step before the seed's: its anchor, if it has one, is the event
-                if (ap != 0 && al >= P.msl) { adv = la; bpos = ap; blen = al; LZ_PS(11); return 1; }
-            } else arbitrate(P, R.len, l, ap, al, sp, sl);
-        }
-        adv = l; bpos = sp; blen = sl;
-        LZ_PS(12); LZ_PSN(14, l);
-        if (close && sp == sp0 && sl == sl0) {
-            LZ_PS(13);
-            ev.masks = true;
-            ev.to_scan = to_scan; ev.nf = nf;
-            ev.Lm = wballot((lane < to_scan) & (((wql ^ w0l) & 3u) != 0));
-            ev.Rm = wballot((lane < to_scan) & sym_differs(y));
-            ev.Bf = wballot((lane < nf) & sym_differs(z));
-        }
-        return 1;
     }
     __device__ __forceinline__ ExtMasks ext_scan(u64 prevB, u64 B, int n) const
     {
