@@ -1227,9 +1227,6 @@ struct DevWave {
             "Lnc_seedev_%=:\n\t" \
             "s_ff1_i32_b64 %[t0], %[m]\n"                   /* l */ \
             "Lnc_sdl_%=:\n\t" \
-            LZ_NC_WHY(1) \
-            "s_cmp_eq_u32 %[t0], %[gap]\n\t" \
-            "s_cbranch_scc1 Lnc_end_%=\n\t"                 /* the queued candidate's own step: arbitration */ \
             "v_readlane_b32 %[t1], %[qk], %[t0]\n\t"        /* the step's msl-mer */ \
             "s_add_i32 %[t2], %[t0], %[MRD]\n\t"            /* its window: the positions idx < l + mrd */ \
             "s_sub_i32 %[kc], %[t2], 64\n\t" \
@@ -1257,6 +1254,18 @@ struct DevWave {
             "s_cselect_b32 %[t2], %[t2], %[kc]\n\t"         /* idx */ \
             "s_add_i32 %[rec], %[rend], %[t2]\n\t"          /* the seed in the reference ... */ \
             "s_add_i32 %[cls], %[i], %[t0]\n\t"             /* ... and in the query */ \
+            /* The queued candidate's own step: its anchor arbitrates with the seed (parser.cpp:604-623) -- unless it IS the */ \
+            /* seed: a plain candidate (resolved by its lane, >= mal, not at position 0) at the seed's own position is the */ \
+            /* homologous mal-mer of a related stretch, same match, nothing to decide; it leaves the queue when the scan has */ \
+            /* passed it (Lnc_top) */ \
+            LZ_NC_WHY(1) \
+            "s_cmp_lg_u32 %[t0], %[gap]\n\t" \
+            "s_cbranch_scc1 Lnc_snoq_%=\n\t" \
+            "s_cmp_lt_i32 %[blen], 1\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            "s_cmp_lg_u32 %[bpos], %[rec]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n" \
+            "Lnc_snoq_%=:\n\t" \
             /* bounds: query [cls + 7, cls + 71) inside [0, Lq), Lq = qend - 33 (qend = the scan's end D - msl = Lq + mrd - msl; a pair */ \
             /* with an N in it has qend far below zero); reference the same inside [0, L) or [rc0, rc0 + L), L = (rlim - C41M) / 2 */ \
             /* (rlim = 2 L + 3 mrd - msl + 1 - 80), rc0 = L + 2 mrd */ \
