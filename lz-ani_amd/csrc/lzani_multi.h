@@ -47,7 +47,34 @@ struct lzani_group {
     bool rehearsal = false;             // the same device listed more than once: shards move by device copies
     std::string err;
     double gather_ms = 0;
+    // buffers of lzani_group_run_rows, kept from call to call and grown when a call needs more (a tiled all2all makes ten
+    // calls of the same size: no allocation after the first): the gathered / CSR-ordered results on the first device, a
+    // shard buffer per peer, the scatter table, and two pinned staging buffers for the copy out
+    int* d_all = nullptr;
+    int* d_final = nullptr;
+    size_t res_cap = 0;                 // results (12 B each) d_all / d_final hold
+    std::vector<int*> d_shard;          // [0] unused (the first device writes into d_all)
+    std::vector<size_t> shard_cap;
+    unsigned long long* d_tab = nullptr;
+    size_t tab_cap = 0;
+    char* h_stage[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
 };
+enum : size_t { GROUP_STAGE_BYTES = (size_t)32 << 20 };
+static void group_free_buffers(lzani_group* g)
+{
+    if (!g->ctx.empty()) hipSetDevice(g->ctx[0]->dev);
+    hipFree(g->d_all); hipFree(g->d_final); hipFree(g->d_tab);
+    g->d_all = g->d_final = nullptr; g->d_tab = nullptr; g->res_cap = g->tab_cap = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (g->h_stage[k]) hipHostFree(g->h_stage[k]);
+        if (g->ev_stage[k]) hipEventDestroy(g->ev_stage[k]);
+        g->h_stage[k] = nullptr; g->ev_stage[k] = nullptr;
+    }
+    for (size_t d = 1; d < g->d_shard.size(); ++d)
+        if (g->d_shard[d]) { hipSetDevice(g->ctx[d]->dev); hipFree(g->d_shard[d]); g->d_shard[d] = nullptr; }
+    g->shard_cap.assign(g->shard_cap.size(), 0);
+}
 
 static void comm_release(lzani_ctx* c)
 {
@@ -203,6 +230,7 @@ int lzani_plan_gather(uint32_t n_rows, const uint64_t* row_off, const uint32_t* 
 void lzani_group_destroy(lzani_group* g)
 {
     if (!g) return;
+    group_free_buffers(g);
     for (auto cm : g->comms) if (cm) ncclCommDestroy(cm);
     for (auto c : g->ctx) lzani_destroy(c);
     delete g;
@@ -309,17 +337,32 @@ int lzani_group_run_rows(lzani_group* g, uint32_t n_rows, const uint32_t* ref_id
         const hipError_t e = hipSetDevice(c0->dev);
         if (e != hipSuccess) return gfail(g, LZANI_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
     }
-    DevBuf<int> d_all, d_final;
-    if (hipMalloc(&d_all.p, std::max<u64>(n_pairs, 1) * 12) != hipSuccess || hipMalloc(&d_final.p, std::max<u64>(n_pairs, 1) * 12) != hipSuccess)
-        return gfail(g, LZANI_ERR_NOMEM, "lzani_group_run_rows: result buffers on device 0");
-    std::vector<int*> d_shard(nd, nullptr);
-    d_shard[0] = d_all.p;
+    // (grown, never shrunk; a failed growth leaves the group without buffers and the call with LZANI_ERR_NOMEM)
+    if (g->res_cap < std::max<u64>(n_pairs, 1)) {
+        hipFree(g->d_all); hipFree(g->d_final);
+        g->d_all = g->d_final = nullptr; g->res_cap = 0;
+        if (hipMalloc(&g->d_all, std::max<u64>(n_pairs, 1) * 12) != hipSuccess || hipMalloc(&g->d_final, std::max<u64>(n_pairs, 1) * 12) != hipSuccess) {
+            (void)hipGetLastError();
+            hipFree(g->d_all); g->d_all = nullptr;
+            return gfail(g, LZANI_ERR_NOMEM, "lzani_group_run_rows: result buffers on device 0");
+        }
+        g->res_cap = std::max<u64>(n_pairs, 1);
+    }
+    int* const d_all = g->d_all;
+    int* const d_final = g->d_final;
+    g->d_shard.resize(nd, nullptr);
+    g->shard_cap.resize(nd, 0);
+    std::vector<int*>& d_shard = g->d_shard;
+    d_shard[0] = d_all;
     std::vector<int> rc(nd, LZANI_OK);
     auto one = [&](u32 d) {
         lzani_ctx* c = g->ctx[d];
         if (sh[d].ref.empty()) { c->tm = lzani_timing{}; return; }       // no row for this device
-        if (d) {
-            if (hipSetDevice(c->dev) != hipSuccess || hipMalloc(&d_shard[d], std::max<u64>(sh[d].off.back(), 1) * 12) != hipSuccess) { rc[d] = LZANI_ERR_NOMEM; return; }
+        if (d && g->shard_cap[d] < std::max<u64>(sh[d].off.back(), 1)) {
+            if (hipSetDevice(c->dev) != hipSuccess) { rc[d] = LZANI_ERR_DEVICE; return; }
+            hipFree(d_shard[d]); d_shard[d] = nullptr; g->shard_cap[d] = 0;
+            if (hipMalloc(&d_shard[d], std::max<u64>(sh[d].off.back(), 1) * 12) != hipSuccess) { (void)hipGetLastError(); d_shard[d] = nullptr; rc[d] = LZANI_ERR_NOMEM; return; }
+            g->shard_cap[d] = std::max<u64>(sh[d].off.back(), 1);
         }
         rc[d] = lzani_run_rows_device(c, (u32)sh[d].ref.size(), sh[d].ref.data(), sh[d].off.data(),
                                       query_ids ? sh[d].q.data() : nullptr, d_shard[d]);
@@ -348,14 +391,14 @@ int lzani_group_run_rows(lzani_group* g, uint32_t n_rows, const uint32_t* ref_id
                 hipSetDevice(g->ctx[d]->dev);
                 r = ncclSend(d_shard[d], cnt, ncclInt32, 0, g->comms[d], g->ctx[d]->stream);
                 hipSetDevice(c0->dev);
-                if (r == ncclSuccess) r = ncclRecv(d_all.p + 3 * sh[d].base, cnt, ncclInt32, (int)d, g->comms[0], c0->stream);
+                if (r == ncclSuccess) r = ncclRecv(d_all + 3 * sh[d].base, cnt, ncclInt32, (int)d, g->comms[0], c0->stream);
             }
             ncclResult_t r2 = ncclGroupEnd();
             if (r == ncclSuccess) r = r2;
             if (r != ncclSuccess) ret = gfail(g, LZANI_ERR_DEVICE, std::string("RCCL gather: ") + ncclGetErrorString(r));
         } else {
             for (u32 d = 1; d < nd; ++d)                         // rehearsal on one device: plain device copies
-                if (sh[d].off.back() && hipMemcpyAsync(d_all.p + 3 * sh[d].base, d_shard[d], sh[d].off.back() * 12, hipMemcpyDeviceToDevice, c0->stream) != hipSuccess)
+                if (sh[d].off.back() && hipMemcpyAsync(d_all + 3 * sh[d].base, d_shard[d], sh[d].off.back() * 12, hipMemcpyDeviceToDevice, c0->stream) != hipSuccess)
                     ret = gfail(g, LZANI_ERR_DEVICE, "device copy of a shard failed");
         }
     }
@@ -366,22 +409,50 @@ int lzani_group_run_rows(lzani_group* g, uint32_t n_rows, const uint32_t* ref_id
             ret = gfail(g, LZANI_ERR_ARG, "lzani_group_run_rows: gather plan");
         for (u32 d = 0; d < nd && ret == LZANI_OK; ++d)
             if (sbase[d] != sh[d].base) ret = gfail(g, LZANI_ERR_STATE, "lzani_group_run_rows: gather plan and shards disagree");
-        DevBuf<u64> d_tab;
-        hipError_t e = ret == LZANI_OK ? d_tab.alloc(tab.size()) : hipErrorInvalidValue;
-        if (e == hipSuccess) e = hipMemcpyAsync(d_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c0->stream);
+        hipError_t e = ret == LZANI_OK ? hipSuccess : hipErrorInvalidValue;
+        if (e == hipSuccess && g->tab_cap < tab.size()) {
+            hipFree(g->d_tab); g->d_tab = nullptr; g->tab_cap = 0;
+            e = hipMalloc(&g->d_tab, tab.size() * 8);
+            if (e == hipSuccess) g->tab_cap = tab.size();
+        }
+        unsigned long long* const d_tab = g->d_tab;
+        if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c0->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_scatter_rows, dim3(n_rows), dim3(256), 0, c0->stream, d_all.p, d_final.p, d_tab.p, d_tab.p + n_rows, d_tab.p + 2 * (size_t)n_rows);
+            hipLaunchKernelGGL(k_scatter_rows, dim3(n_rows), dim3(256), 0, c0->stream, d_all, d_final, (const u64*)d_tab, (const u64*)d_tab + n_rows, (const u64*)d_tab + 2 * (size_t)n_rows);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipEventRecord(e1, c0->stream);
-        if (e == hipSuccess && n_pairs) e = hipMemcpyAsync(out, d_final.p, n_pairs * 12, hipMemcpyDeviceToHost, c0->stream);
+        // the copy out: through two pinned staging buffers that take turns -- the device-to-host copy of one piece flies
+        // while the host moves the piece before it into the caller's (pageable) buffer
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            if (!g->h_stage[k]) e = hipHostMalloc((void**)&g->h_stage[k], GROUP_STAGE_BYTES, hipHostMallocDefault);
+            if (e == hipSuccess && !g->ev_stage[k]) e = hipEventCreateWithFlags(&g->ev_stage[k], hipEventDisableTiming);
+        }
+        {
+            const size_t total = (size_t)n_pairs * 12;
+            size_t issued = 0, moved = 0;
+            size_t len[2] = {0, 0};
+            for (int k = 0; e == hipSuccess && (issued < total || moved < total); k ^= 1) {
+                if (len[k]) {                                  // the piece this buffer holds: wait for it, hand it over
+                    e = hipEventSynchronize(g->ev_stage[k]);
+                    if (e == hipSuccess) memcpy((char*)out + moved, g->h_stage[k], len[k]);
+                    moved += len[k];
+                    len[k] = 0;
+                }
+                if (e == hipSuccess && issued < total) {
+                    len[k] = std::min<size_t>(GROUP_STAGE_BYTES, total - issued);
+                    e = hipMemcpyAsync(g->h_stage[k], (const char*)d_final + issued, len[k], hipMemcpyDeviceToHost, c0->stream);
+                    if (e == hipSuccess) e = hipEventRecord(g->ev_stage[k], c0->stream);
+                    issued += len[k];
+                }
+            }
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
         for (u32 d = 1; d < nd && e == hipSuccess; ++d) { hipSetDevice(g->ctx[d]->dev); e = hipStreamSynchronize(g->ctx[d]->stream); }
         if (ret != LZANI_OK) {}                                   // (the gather plan failed: its message stands)
         else if (e != hipSuccess) ret = gfail(g, LZANI_ERR_DEVICE, std::string("gather / copy out: ") + hipGetErrorString(e));
         else { float ms = 0; hipEventElapsedTime(&ms, e0, e1); g->gather_ms = ms; }
     }
-    for (u32 d = 1; d < nd; ++d) if (d_shard[d]) { hipSetDevice(g->ctx[d]->dev); hipFree(d_shard[d]); }
     hipSetDevice(c0->dev);
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
