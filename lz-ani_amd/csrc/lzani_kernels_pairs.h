@@ -68,6 +68,9 @@ template <int CHAIN> struct ChainP {
            NT = MQD + 1, WIN = MQD + MRD };
 };
 
+#ifndef LZANI_STRETCH_DENSE
+#define LZANI_STRETCH_DENSE 0
+#endif
 template <bool FAST, bool BK = false, bool JOIN = false, int CHAIN = 0, bool LFLT = false>
 struct DevWave {
     static constexpr bool NULL_CHAIN = CHAIN != 0;      // (see ChainP)
@@ -1604,9 +1607,6 @@ struct DevWave {
     // compiler's path (profiles/r4_related_*: the related kernel is bound by instruction issue, the scalar unit first).
     // (in the kernels where related pairs are what the time goes into: filtered rows -- the probe form -- and the bitmap forms of
     // the long-genome parameter sets; the dense viral kernel, 999 unrelated pairs in 1,000, stays lean: the loop costs it 2.5 %)
-#ifndef LZANI_STRETCH_DENSE
-#define LZANI_STRETCH_DENSE 0
-#endif
     static constexpr bool HAS_STRETCH_CHAIN = CHAIN != 0 && (ChainP<CHAIN>::MQD <= ChainP<CHAIN>::MRD) &&
                                               (!JOIN || ChainP<CHAIN>::MAL >= 13 || LZANI_STRETCH_DENSE);
     // kind: 0 = nothing in hand; 1 = the last event's gap and match are committed, its forward extension is not: Bf = the

@@ -1,0 +1,6 @@
+#!/bin/bash
+# GPU box: path counters and section shares of the related workload (diagnostic builds)
+set -o pipefail
+mkdir -p gpurun_out
+bash tools/r4_paths.sh || exit 1
+bash tools/r4_stamps.sh
