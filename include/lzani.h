@@ -139,6 +139,10 @@ typedef struct lzani_layout_info {
                                              * (dense rows: presence matrix of the batch's references)                 */
     int32_t  rtc_launches;                  /* pair-kernel launches of the last run by a kernel compiled at run time for
                                              * this context's parameters (lzani_get_rtc_info)                          */
+    int32_t  lpt_launches;                  /* pair-kernel launches of the last run that handed their tickets out longest pair
+                                             * first (batches of few, long pairs; placement only)                      */
+    int32_t  matrix_from_index;             /* presence matrices of the last run made from the batch's anchor indexes
+                                             * (long genomes: no global atomics) instead of one atomicOr per text position */
 } lzani_layout_info;
 int lzani_get_layout(const lzani_ctx *ctx, lzani_layout_info *info);
 
@@ -224,6 +228,12 @@ int lzani_plan_gather(uint32_t n_rows, const uint64_t *row_off, const uint32_t *
  * fill order, which no reader of the index depends on. */
 int lzani_debug_get_index(lzani_ctx *ctx, uint32_t id, uint64_t *t2, uint64_t *nm,
                           uint32_t *dirz, uint32_t *ent, uint32_t *n_ent, uint32_t *geom);
+
+/* Test hook: the engine's own radix sort of 64-bit keys (csrc/lzani_sort.hip; it orders the k-mers of a long reference
+ * into its anchor index in place of the hash-table fill of prepare_ht_long, parser.cpp:146-189) on host arrays: n_seg
+ * segments of seg_len keys each, every segment sorted by itself, stably, by the key bits [begin_bit, end_bit). */
+int lzani_debug_sort_segments(lzani_ctx *ctx, const uint64_t *keys, uint64_t *out, uint64_t seg_len, uint32_t n_seg,
+                              int begin_bit, int end_bit);
 
 #ifdef __cplusplus
 }

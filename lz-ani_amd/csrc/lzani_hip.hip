@@ -32,8 +32,10 @@ __device__ unsigned long long g_phase_time[4];
 __device__ unsigned long long g_path_stats[36];
 #endif
 
+int lzani_sort_segments(const unsigned long long* in, unsigned long long* out, size_t seg_len, size_t n_seg, int begin_bit, int end_bit,
+                        void* tmp, size_t* tmp_bytes, hipStream_t stream);
 int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_t n, int begin_bit, int end_bit,
-                    void* tmp, size_t* tmp_bytes, hipStream_t stream);      // lzani_sort.hip (hipCUB radix sort)
+                    void* tmp, size_t* tmp_bytes, hipStream_t stream);      // lzani_sort.hip (the engine's own radix sort)
 
 #include "lzani_core.h"
 #include "lzani_layout.h"
@@ -118,7 +120,13 @@ struct lzani_ctx {
     u32* d_pm_pidx = nullptr;     // rows with query lists: pair of (query, slot of the group), query flags + list + count behind it
     size_t pm_pidx_bytes = 0;
     int pm_launches = 0;          // pair-kernel launches of the last run fed by candidate bitmaps
+    u32* d_lpt_cnt = nullptr;     // batches of few, long pairs: candidates per pair, then the ticket keys unsorted / sorted
+    unsigned long long* d_lpt_keys = nullptr;
+    size_t lpt_pairs = 0;
+    int lpt_launches = 0;         // pair-kernel launches of the last run that took their tickets longest pair first
+    int pmfi_launches = 0;        // presence matrices of the last run made by k_pm_from_index
     bool pm_attr_set = false;
+    u32 pmfi_attr_set = 0;                // k_pm_from_index<RW>: bit RW = its LDS limit is raised
 
     lzani_timing tm{};
     // pair kernels compiled at run time for this context's parameters (lzani_rtc.h); none for the two ahead-of-time tuples
@@ -179,8 +187,9 @@ void free_genomes(lzani_ctx* c)
 }
 void free_pm(lzani_ctx* c)
 {
-    hipFree(c->d_pm); hipFree(c->d_pm_cbits); hipFree(c->d_pm_pidx);
+    hipFree(c->d_pm); hipFree(c->d_pm_cbits); hipFree(c->d_pm_pidx); hipFree(c->d_lpt_cnt); hipFree(c->d_lpt_keys);
     c->d_pm = c->d_pm_cbits = c->d_pm_pidx = nullptr; c->pm_bytes = c->pm_cbits_bytes = c->pm_pidx_bytes = 0;
+    c->d_lpt_cnt = nullptr; c->d_lpt_keys = nullptr; c->lpt_pairs = 0;
 }
 void free_slabs(lzani_ctx* c)
 {
@@ -421,16 +430,16 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows, bool with_filter
         c->tm.index_launches += 1;
     }
     if (c->sort_build) {
-        // keys -> radix sort (groups of slots below 2^30 keys) -> the tables in one streaming pass
-        const int shift_slot = c->geo.kb + c->geo.posbits, slotbits = ceil_log2((u64)rows + 1);     // (no slot number is all ones: see build_join_lists)
+        // keys -> radix sort, every slot a segment of its own (lzani_sort.hip) -> the tables in one streaming pass.  A key is
+        // hash || position; a position without a k-mer is all ones and sorts behind the slot's keys by the one bit above the hash.
+        const int shift_slot = c->geo.kb + c->geo.posbits;
         const u64 Tm = (u64)c->Tmax;
-        const u32 group = (u32)std::max<u64>(1, std::min<u64>(rows, (1ull << 30) / std::max<u64>(Tm, 1)));
+        const u32 group = 1;
         HIPCHK(c, hipMemsetAsync(c->d_icnt, 0, (size_t)rows * 4, c->stream));
         hipLaunchKernelGGL(k_idx_keys, dim3((u32)((Tm + 4095) / 4096), rows), dim3(256), 0, c->stream, ia, c->d_ikeys_in, c->d_icnt, c->Tmax, shift_slot);
-        for (u32 s0 = 0; s0 < rows; s0 += group) {
-            const u64 keys = (u64)std::min(group, rows - s0) * Tm;
+        {
             size_t need = 0;
-            int e = lzani_sort_keys(c->d_ikeys_in + s0 * Tm, c->d_ikeys + s0 * Tm, keys, c->geo.posbits, shift_slot + slotbits, nullptr, &need, c->stream);
+            int e = lzani_sort_segments(c->d_ikeys_in, c->d_ikeys, Tm, rows, c->geo.posbits, shift_slot + 1, nullptr, &need, c->stream);
             if (e != 0) return fail(c, LZANI_ERR_DEVICE, "index build: radix sort (size query) failed");
             if (need > c->jtmp_bytes) {
                 HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -439,7 +448,7 @@ int build_indexes(lzani_ctx* c, const u32* d_ref_ids, u32 rows, bool with_filter
                 c->jtmp_bytes = need;
             }
             need = c->jtmp_bytes;
-            e = lzani_sort_keys(c->d_ikeys_in + s0 * Tm, c->d_ikeys + s0 * Tm, keys, c->geo.posbits, shift_slot + slotbits, c->d_jtmp, &need, c->stream);
+            e = lzani_sort_segments(c->d_ikeys_in, c->d_ikeys, Tm, rows, c->geo.posbits, shift_slot + 1, c->d_jtmp, &need, c->stream);
             if (e != 0) return fail(c, LZANI_ERR_DEVICE, "index build: radix sort failed");
         }
         hipLaunchKernelGGL(k_idx_base, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_icnt, c->d_ibase, rows, group, Tm);
@@ -495,6 +504,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     c->batches_last_run = 0;
     c->blk_launches = 0;
     c->pm_launches = 0;
+    c->lpt_launches = 0;
+    c->pmfi_launches = 0;
     c->rtc_launches = 0;
     if (n_rows == 0) return LZANI_OK;
     const u64 n_pairs = row_off[n_rows];
@@ -555,8 +566,11 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         // Query lists qualify when they are dense where they are: a query that occurs in a group of rows should meet a
         // good part of it (one matrix row read serves all its pairs of the group) -- the row x column blocks of a tiled
         // all2all do, the few relatives a kmer-db filter leaves per row do not.  No query twice in a row (one bitmap each).
+        // (Measured in round 4 on the related workload, families of 50 in length order -- 16 pairs per query and group:
+        // the pair kernel gains 18 % from the bitmaps, the candidate stage costs more than that; against the ROUNDS of the
+        // first kernel -- no tag words: long k-mers on mid-size genomes -- the bitmaps win from two pairs per query on.)
         const char* sh = getenv("LZANI_PM_MIN_SHARE");
-        const u64 min_share = sh ? strtoull(sh, nullptr, 10) : 48;
+        const u64 min_share = sh ? strtoull(sh, nullptr, 10) : c->tw_stride ? 48 : 2;
         const bool lists_ok = !query_ids || (!lists_dup && n_pairs >= min_share * lists_involved);
         pm = !rs && lists_ok && c->d_kmL && c->bk_stride && c->P.mqd + c->P.mrd <= 128 && c->geo.kb <= 30 &&
              c->n >= 2 && n_rows >= min_rows && !(e && *e == '0');
@@ -717,6 +731,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     // its code, the hand-written null chain included (bitmap and join forms)
     const bool lgp = q.mal == 15 && q.msl == 9 && q.mrd == 40 && q.mqd == 40 && q.reg == 60 && q.aw == 15 && q.am == 7 && q.ar == 3;
     std::vector<char> launched(n_batches, 0);
+    std::vector<u32> grp_seen;                               // (query lists + candidate bitmaps) the group a query was last seen in
+    u32 grp_stamp = 0;
     const char* const bkenv = getenv("LZANI_BLOCK_KERNEL");
     DevBuf<unsigned long long> d_cbits;                      // join form: one candidate bitmap per resident wave
     u64 cbits_stride = 0;
@@ -757,6 +773,26 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         rc = build_indexes(c, d_ref + k0, rows, blk_rows);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(ev[1], c->stream));
+        // Few, long pairs (the batch leaves a wave slot only a few of them): the launch is over when its slowest pair is, so
+        // the pairs with the most candidates -- the related ones -- go first (k_pm_cand counts, k_lpt_keys + a sort order)
+        bool lpt = false;
+        if (pm && e1 > e0) {
+            const char* le = getenv("LZANI_LPT");
+            const u64 bp = e1 - e0;
+            lpt = !rs && bp >= 2 && bp <= (u64)max_blocks * 4 * 32 && (le ? *le == '1' : cb_words >= 8192);     // (queries from ~256 kbp on)
+            if (le && *le == '0') lpt = false;
+            if (lpt && c->lpt_pairs < bp) {
+                hipFree(c->d_lpt_cnt); hipFree(c->d_lpt_keys);
+                c->d_lpt_cnt = nullptr; c->d_lpt_keys = nullptr; c->lpt_pairs = 0;
+                if (hipMalloc(&c->d_lpt_cnt, (size_t)bp * 4) != hipSuccess || hipMalloc(&c->d_lpt_keys, (size_t)bp * 16) != hipSuccess) {
+                    (void)hipGetLastError();
+                    hipFree(c->d_lpt_cnt); hipFree(c->d_lpt_keys);
+                    c->d_lpt_cnt = nullptr; c->d_lpt_keys = nullptr;
+                    lpt = false;                                 // (placement only: the run goes on without it)
+                } else c->lpt_pairs = (size_t)bp;
+            }
+            if (lpt) HIPCHK(c, hipMemsetAsync(c->d_lpt_cnt, 0, (size_t)bp * 4, c->stream));
+        }
         if (pm && e1 > e0) {
             // candidate bitmaps of the batch's pairs, group by group of PM_GROUP references
             for (u32 g0 = 0; g0 < rows; g0 += pm_group) {
@@ -768,6 +804,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 pg.mal = c->P.mal; pg.mrd = c->P.mrd;
                 pg.cbits = c->d_pm_cbits; pg.cb_words = cb_words; pg.e0 = e0; pg.n = c->n; pg.q0 = 0;
                 pg.query_ids = d_q.p; pg.pidx = nullptr; pg.qflag = pg.qlist = pg.qcount = nullptr;
+                pg.pcount = lpt ? c->d_lpt_cnt : nullptr;
                 if (query_ids) {                            // the lists of the group's rows -> pair table + the queries involved
                     const size_t tab = (size_t)c->n * 32 * pg.rw;
                     pg.pidx = c->d_pm_pidx; pg.qflag = c->d_pm_pidx + (size_t)c->n * pm_group; pg.qlist = pg.qflag + c->n; pg.qcount = pg.qlist + c->n;
@@ -775,8 +812,35 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                     HIPCHK(c, hipMemsetAsync(pg.qflag, 0, ((size_t)2 * c->n + 1) * 4, c->stream));
                     hipLaunchKernelGGL(k_pm_pairs, dim3(pg.rows), dim3(256), 0, c->stream, pg);
                 }
-                HIPCHK(c, hipMemsetAsync(c->d_pm, 0, ((size_t)1 << pm_bits) * pg.rw * 4, c->stream));
-                hipLaunchKernelGGL(k_pm_build, dim3((u32)std::min<u64>(((u64)c->Tmax + 255) / 256, 64), pg.rows), dim3(256), 0, c->stream, pg, c->Tmax);
+                // the matrix: from the group's indexes, chunk by chunk through LDS (long genomes: no global atomics, no clearing),
+                // or by one atomicOr per text position into the cleared matrix
+                const int tbits = c->geo.kb - c->geo.dirbits;
+                const int rcl = std::min(pm_bits, pg.rw <= 4 ? 13 : pg.rw <= 8 ? 12 : 11);
+                const char* fie = getenv("LZANI_PM_FROM_INDEX");
+                const bool from_index = c->geo.tagmask == (u32)lowmask(tbits) && pm_bits == c->geo.kb && rcl >= tbits &&
+                                        (fie ? *fie == '1' : pm_bits > 24);
+                if (from_index) {
+                    c->pmfi_launches += 1;
+                    const size_t fl = ((size_t)pg.rw << rcl) * 4;
+                    const dim3 gi(1u << (pm_bits - rcl)), bi(1024);
+#define LZ_PM_FI(RW) do { \
+                        if (!(c->pmfi_attr_set & (1u << RW))) { \
+                            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pm_from_index<RW>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+                            c->pmfi_attr_set |= 1u << RW; \
+                        } \
+                        hipLaunchKernelGGL(k_pm_from_index<RW>, gi, bi, fl, c->stream, pg, c->d_dirz, c->d_ent, c->dir_stride, c->ent_stride, tbits, c->geo.posbits, rcl); \
+                    } while (0)
+                    switch (pg.rw) {
+                    case 4: LZ_PM_FI(4); break;
+                    case 8: LZ_PM_FI(8); break;
+                    case 12: LZ_PM_FI(12); break;
+                    default: LZ_PM_FI(16); break;
+                    }
+#undef LZ_PM_FI
+                } else {
+                    HIPCHK(c, hipMemsetAsync(c->d_pm, 0, ((size_t)1 << pm_bits) * pg.rw * 4, c->stream));
+                    hipLaunchKernelGGL(k_pm_build, dim3((u32)std::min<u64>(((u64)c->Tmax + 255) / 256, 64), pg.rows), dim3(256), 0, c->stream, pg, c->Tmax);
+                }
                 const u32 rp = 32 * pg.rw;
                 const size_t lds = (size_t)(PM_TILE_WORDS * (rp + 1) + rp) * 4;
                 if (!c->pm_attr_set) {
@@ -787,9 +851,20 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pm_cand<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmax));
                     c->pm_attr_set = true;
                 }
-                for (u32 q0 = 0; q0 < c->n; q0 += 32768) {     // gridDim.y is limited to 65535
+                // (query lists: one row of blocks per query that occurs in the group -- counted here, the device list is
+                // k_pm_pairs' -- not per genome: 20,000 genomes x 44 tiles of blocks that find nothing to do were most of
+                // the candidate stage of a filtered run)
+                u32 nq = c->n;
+                if (query_ids) {
+                    if (grp_seen.size() != c->n) grp_seen.assign(c->n, 0xFFFFFFFFu);
+                    const u32 stamp = ++grp_stamp;
+                    nq = 0;
+                    for (u64 e = row_off[k0 + g0]; e < row_off[k0 + g0 + pg.rows]; ++e)
+                        if (grp_seen[query_ids[e]] != stamp) { grp_seen[query_ids[e]] = stamp; ++nq; }
+                }
+                for (u32 q0 = 0; q0 < nq; q0 += 32768) {       // gridDim.y is limited to 65535
                     pg.q0 = q0;
-                    const dim3 gc(pm_tiles, std::min<u32>(32768, c->n - q0)), bc(256);
+                    const dim3 gc(pm_tiles, std::min<u32>(32768, nq - q0)), bc(256);
                     switch (pg.rw / 4) {
                     case 1: hipLaunchKernelGGL(k_pm_cand<1>, gc, bc, lds, c->stream, pg); break;
                     case 2: hipLaunchKernelGGL(k_pm_cand<2>, gc, bc, lds, c->stream, pg); break;
@@ -798,6 +873,24 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                     }
                 }
                 c->tm.cand_launches += 2;
+            }
+            if (lpt) {                                       // the ticket order of the batch's queues
+                const u64 bp = e1 - e0;
+                QueueBounds qbv;
+                for (int x = 0; x <= NQUEUES; ++x) qbv.v[x] = qb[(size_t)b * (NQUEUES + 1) + x];
+                hipLaunchKernelGGL(k_lpt_keys, dim3((u32)std::min<u64>((bp + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                                   d_qorder + k0, d_qcum + k0 + b, qbv, d_off + k0, e0, c->d_lpt_cnt, c->d_lpt_keys, rows, bp);
+                size_t need = 0;
+                int e = lzani_sort_keys(c->d_lpt_keys, c->d_lpt_keys + bp, bp, 32, 56, nullptr, &need, c->stream);
+                if (e == 0 && need > c->jtmp_bytes) {
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    hipFree(c->d_jtmp); c->d_jtmp = nullptr; c->jtmp_bytes = 0;
+                    HIPCHK(c, hipMalloc(&c->d_jtmp, need));
+                    c->jtmp_bytes = need;
+                }
+                need = c->jtmp_bytes;
+                if (e == 0) e = lzani_sort_keys(c->d_lpt_keys, c->d_lpt_keys + bp, bp, 32, 56, c->d_jtmp, &need, c->stream);
+                if (e != 0) return fail(c, LZANI_ERR_DEVICE, "ticket order: radix sort failed");
             }
             HIPCHK(c, hipGetLastError());
         }
@@ -819,6 +912,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.cbits = d_cbits.p; pa.cbits_stride = cbits_stride; pa.cb_e0 = 0;
             if (pm) { pa.cbits = reinterpret_cast<unsigned long long*>(c->d_pm_cbits); pa.cbits_stride = cb_words / 2; pa.cb_e0 = e0; }
             pa.reg_out = rs ? rs->d_regions : nullptr; pa.reg_count = rs ? rs->d_count : nullptr; pa.reg_cap = rs ? rs->capacity : 0;
+            pa.torder = lpt ? c->d_lpt_keys + (e1 - e0) : nullptr;
+            c->lpt_launches += lpt ? 1 : 0;
             HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, NQUEUES * sizeof(unsigned long long), c->stream));
             const u64 waves = e1 - e0;
             const dim3 gd((u32)std::min<u64>((waves + 3) / 4, max_blocks)), bd(256);
@@ -1232,6 +1327,7 @@ int lzani_get_layout(const lzani_ctx* c, lzani_layout_info* o)
     o->bytes_per_slot = 4 * (c->dir_stride + c->ent_stride + c->bk_stride + c->tw_stride + c->fl_stride);
     o->bytes_genomes = c->total_nm * (16 + 8) + (c->d_kmL ? c->total_nm * 64 * 8 : 0);
     o->join_lists = c->join_mode; o->block_launches = c->blk_launches; o->bitmap_launches = c->pm_launches; o->rtc_launches = c->rtc_launches;
+    o->lpt_launches = c->lpt_launches; o->matrix_from_index = c->pmfi_launches;
     return LZANI_OK;
 }
 
@@ -1286,6 +1382,30 @@ int lzani_debug_get_index(lzani_ctx* c, uint32_t id, uint64_t* t2, uint64_t* nm,
     if (ent && ne) HIPCHK(c, hipMemcpy(ent, c->d_ent, (size_t)ne * 4, hipMemcpyDeviceToHost));
     if (n_ent) *n_ent = ne;
     if (geom) { geom[0] = c->geo.kb; geom[1] = c->geo.dirbits; geom[2] = c->geo.posbits; geom[3] = c->geo.tagmask; }
+    return LZANI_OK;
+}
+
+// Test hook: the engine's radix sort (lzani_sort.hip) on host keys -- n_seg segments of seg_len keys, each sorted on its own by
+// the bits [begin_bit, end_bit), stably.
+int lzani_debug_sort_segments(lzani_ctx* c, const uint64_t* keys, uint64_t* out, uint64_t seg_len, uint32_t n_seg, int begin_bit, int end_bit)
+{
+    if (!c || !keys || !out) return LZANI_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->dev));
+    const size_t n = (size_t)seg_len * n_seg;
+    if (n == 0) return LZANI_OK;
+    DevBuf<unsigned long long> d_in, d_out;
+    DevBuf<unsigned char> d_tmp;
+    HIPCHK(c, d_in.alloc(n));
+    HIPCHK(c, d_out.alloc(n));
+    HIPCHK(c, hipMemcpy(d_in.p, keys, n * 8, hipMemcpyHostToDevice));
+    size_t need = 0;
+    if (lzani_sort_segments(d_in.p, d_out.p, seg_len, n_seg, begin_bit, end_bit, nullptr, &need, c->stream) != 0)
+        return fail(c, LZANI_ERR_ARG, "lzani_debug_sort_segments: bad arguments");
+    HIPCHK(c, d_tmp.alloc(need));
+    if (lzani_sort_segments(d_in.p, d_out.p, seg_len, n_seg, begin_bit, end_bit, d_tmp.p, &need, c->stream) != 0)
+        return fail(c, LZANI_ERR_DEVICE, "lzani_debug_sort_segments: sort failed");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, d_out.p, n * 8, hipMemcpyDeviceToHost));
     return LZANI_OK;
 }
 

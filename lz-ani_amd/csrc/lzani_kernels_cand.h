@@ -49,6 +49,9 @@ struct PmArgs {
     u32* qflag;
     u32* qlist;
     u32* qcount;
+    // batches of few, long pairs: pcount[pair of the batch] += the pair's candidates (the pair kernel then takes the pairs
+    // with the most candidates -- the related ones, ten times the work of a chance pair -- first); nullptr = not counted
+    u32* pcount;
 };
 
 // One thread per text position of the group's references: the slot's bit in the row of the position's mal-mer.
@@ -63,6 +66,57 @@ __global__ void __launch_bounds__(256) k_pm_build(PmArgs a, int Tmax)
         const u32 h = km[p];
         if (h != KM_INVALID) atomicOr(&a.M[(u64)(h & a.mmask) * a.rw + w], bit);
     }
+}
+
+// The same matrix straight from the group's anchor indexes, without a global atomic and without clearing it first (round 4;
+// long genomes: 1.3 G memory-side atomicOr per 128 x 5 Mbp references were 70 ms of a 480 ms step).  The index of a slot
+// is its mal-mers sorted by mixed hash -- bucket = the hash's top dirbits (directory), the rest the entry's tag, exact
+// here -- so the matrix rows [c << rcl, (c + 1) << rcl) are the buckets [c << (rcl - tb), ..) of EVERY slot: one block
+// per chunk c reads those few buckets of each slot (a contiguous piece of its directory and of its entries), sets the
+// bits in an LDS copy of the chunk and writes the chunk out whole -- every matrix row exactly once, coalesced.
+//   needs: tags exact (tagmask = all tb bits), row = hash (mbits = kb), rcl >= tb
+template <int RW>          // words per matrix row
+__global__ void __launch_bounds__(1024) k_pm_from_index(PmArgs a, const u32* __restrict__ dirz, const u32* __restrict__ ent,
+                                                        u64 dir_stride, u64 ent_stride, int tb, int posbits, int rcl)
+{
+    extern __shared__ u32 s_rows[];                    // (1 << rcl) rows of RW words
+    const u32 nwords = (u32)RW << rcl, nbk_l2 = (u32)(rcl - tb), nbk = 1u << nbk_l2;
+    const u32 b0 = blockIdx.x << nbk_l2;
+    for (u32 k = threadIdx.x; k < nwords; k += 1024) s_rows[k] = 0;
+    __syncthreads();
+    const u32 items = a.rows << nbk_l2;                // (slot of the group, bucket of the chunk)
+    enum { U = 8 };
+    for (u32 it0 = threadIdx.x; it0 < items; it0 += U * 1024) {
+        u32 s[U], e[U], first[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {                  // the buckets' entry ranges, all requests first
+            const u32 it = it0 + (u32)k * 1024u;
+            s[k] = e[k] = 0;
+            if (it < items) {
+                const u32* d = dirz + (u64)(a.slot0 + (it >> nbk_l2)) * dir_stride + b0 + (it & (nbk - 1));
+                s[k] = d[0]; e[k] = d[1];
+            }
+            if (e[k] < s[k] || e[k] - s[k] > (1u << 28)) { LZ_GUARD_TRIP(8); e[k] = s[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {                  // a bucket holds 0.6 entries on average: the first of each, together
+            const u32 it = it0 + (u32)k * 1024u;
+            first[k] = s[k] < e[k] ? ent[(u64)(a.slot0 + (it >> nbk_l2)) * ent_stride + s[k]] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (s[k] >= e[k]) continue;
+            const u32 it = it0 + (u32)k * 1024u, slot = it >> nbk_l2, rbase = (it & (nbk - 1)) << tb;
+            const u32 bit = 1u << (slot & 31), w = slot >> 5;
+            atomicOr(&s_rows[(rbase | (first[k] >> posbits)) * RW + w], bit);
+            const u32* v = ent + (u64)(a.slot0 + slot) * ent_stride;
+            for (u32 j = s[k] + 1; j < e[k]; ++j) atomicOr(&s_rows[(rbase | (v[j] >> posbits)) * RW + w], bit);
+        }
+    }
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(a.M + ((u64)blockIdx.x << rcl) * RW);
+    const uint4* src = reinterpret_cast<const uint4*>(s_rows);
+    for (u32 k = threadIdx.x; k < nwords / 4; k += 1024) out[k] = src[k];
 }
 
 // Rows with query lists: one block per slot of the group walks the row's list (no query twice in a row: the host checks).
@@ -146,8 +200,35 @@ __global__ void __launch_bounds__(256) k_pm_cand(PmArgs a)
     const u32 c = threadIdx.x & 31;
     for (u32 s = threadIdx.x >> 5; s < a.rows; s += 8) {
         const u32 pe = s_pair[s];
-        if (pe == 0xFFFFFFFFu) continue;
-        a.cbits[(u64)pe * a.cb_words + (u64)blockIdx.x * PM_TILE_WORDS + c] = s_tile[pm_tile_at(rp1, c, s)];
+        const u32 wv = s_tile[pm_tile_at(rp1, c, s)];
+        if (pe != 0xFFFFFFFFu) a.cbits[(u64)pe * a.cb_words + (u64)blockIdx.x * PM_TILE_WORDS + c] = wv;
+        if (a.pcount) {                                // (block-uniform) the tile's candidates of this pair: one atomic per line
+            u32 n = pe != 0xFFFFFFFFu ? (u32)__builtin_popcount(wv) : 0u;
+            for (int d = 16; d >= 1; d >>= 1) n += __shfl_xor(n, d, 32);
+            if (c == 0 && n) atomicAdd(&a.pcount[pe], n);
+        }
+    }
+}
+
+// Longest pairs first (batches of few, long pairs: a 5 Mbp launch is over when its slowest pair is, and a related pair
+// is ten chance pairs' work).  One key per pair ticket of the batch -- its XCD queue, then the pair's candidate count
+// descending (k_pm_cand's pcount), then the ticket -- sorted, the low words are the order the queues hand their tickets out
+// in (PairArgs::torder).  Placement only: every pair is still computed once, by the same code.
+struct QueueBounds { u32 v[9]; };              // rows [v[x], v[x + 1]) of the batch's queue order belong to XCD queue x
+__global__ void __launch_bounds__(256) k_lpt_keys(const u32* __restrict__ qorder, const u64* __restrict__ qcum, QueueBounds qb8,
+                                                  const u64* __restrict__ row_off, u64 e0, const u32* __restrict__ pcount,
+                                                  unsigned long long* __restrict__ keys, u32 rows, u64 n_tickets)
+{
+    const u64 base = qcum[0];
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n_tickets; t += (u64)gridDim.x * blockDim.x) {
+        u32 lo = 0, hi = rows;                          // the row of ticket t: the last one with qcum[row] <= base + t
+        while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (qcum[mid] <= base + t) lo = mid; else hi = mid; }
+        u32 x = 0;
+        while (x + 1 < 8 && lo >= qb8.v[x + 1]) ++x;      // its queue
+        const u64 e = row_off[qorder[lo]] + (base + t - qcum[lo]);
+        const u32 cnt = pcount[e - e0];
+        const u32 inv = 0xFFFFFu - (cnt > 0xFFFFFu ? 0xFFFFFu : cnt);
+        keys[t] = ((unsigned long long)x << 52) | ((unsigned long long)inv << 32) | (unsigned long long)t;
     }
 }
 

@@ -169,9 +169,12 @@ __global__ void __launch_bounds__(256) k_idx_keys(IdxArgs a, unsigned long long*
         if (p >= Tmax) break;
         const u32 h = p < T ? km[p] : KM_INVALID;
         const bool ok = h != KM_INVALID;
-        out[p] = ok ? ((unsigned long long)slot << shift_slot) | ((unsigned long long)h << a.geo.posbits) | (unsigned long long)p : ~0ULL;
+        // (every slot is sorted as a segment of its own: no slot number in the key; the bit above the hash -- shift_slot -- is
+        // clear in a key and set in the all-ones filler of a position without a k-mer)
+        out[p] = ok ? ((unsigned long long)h << a.geo.posbits) | (unsigned long long)p : ~0ULL;
         mine += ok;
     }
+    (void)shift_slot;
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
     __syncthreads();

@@ -2413,6 +2413,10 @@ struct PairArgs {
     lzani_region* reg_out;        // alignment instantiation only
     unsigned long long* reg_count;
     unsigned long long reg_cap;
+    // batches of few, long pairs: the order a queue hands its tickets out in -- ticket t of the batch (counted through the
+    // queues) stands for ticket (u32)torder[t] of the same queue, the pairs with the most anchor candidates first
+    // (k_lpt_keys, lzani_kernels_cand.h); nullptr = as they come
+    const unsigned long long* torder;
 };
 
 __device__ __forceinline__ u32 xcc_id()
@@ -2567,8 +2571,10 @@ __device__ __forceinline__ void pairs_loop(const PairArgs& a)
             qx = (qx + 1) % NQUEUES;
             continue;
         }
-        const u32 lo = row_of_ticket(a.qcum, rb, re, tk);
-        pair_body<FAST, NFREE, DEFP, ALN, BK, CAND, false>(a, lo, (u32)(tk - a.qcum[lo]), lane, lds, nullptr);
+        u64 tk2 = tk;
+        if (CAND == 2 && a.torder) tk2 = a.qcum[0] + (u32)a.torder[tk - a.qcum[0]];
+        const u32 lo = row_of_ticket(a.qcum, rb, re, tk2);
+        pair_body<FAST, NFREE, DEFP, ALN, BK, CAND, false>(a, lo, (u32)(tk2 - a.qcum[lo]), lane, lds, nullptr);
     }
 }
 template <bool FAST, bool NFREE, int DEFP, bool ALN = false, bool BK = false, int CAND = 0>

@@ -30,7 +30,8 @@ EXPORTS = ("lzani_default_params", "lzani_create", "lzani_destroy", "lzani_last_
            "lzani_debug_get_index", "lzani_run_rows_regions", "lzani_get_layout",
            "lzani_row_costs", "lzani_partition_rows", "lzani_comm_unique_id", "lzani_comm_init", "lzani_comm_allgather",
            "lzani_comm_gatherv", "lzani_group_create", "lzani_group_destroy", "lzani_group_last_error",
-           "lzani_group_set_genomes", "lzani_group_run_rows", "lzani_group_get_timing", "lzani_plan_gather", "lzani_get_rtc_info", "lzani_debug_rtc_compile")
+           "lzani_group_set_genomes", "lzani_group_run_rows", "lzani_group_get_timing", "lzani_plan_gather", "lzani_get_rtc_info", "lzani_debug_rtc_compile",
+           "lzani_debug_sort_segments")
 
 
 class LzaniError(RuntimeError):
@@ -48,7 +49,8 @@ class LayoutInfo(C.Structure):
                 ("kmer_words", C.c_int32), ("bucket_table", C.c_int32), ("tag_words", C.c_int32), ("n_free", C.c_int32),
                 ("slots", C.c_uint32), ("batches_last_run", C.c_uint32), ("bytes_per_slot", C.c_uint64),
                 ("bytes_genomes", C.c_uint64), ("join_lists", C.c_int32), ("block_launches", C.c_int32),
-                ("bitmap_launches", C.c_int32), ("rtc_launches", C.c_int32)]
+                ("bitmap_launches", C.c_int32), ("rtc_launches", C.c_int32),
+                ("lpt_launches", C.c_int32), ("matrix_from_index", C.c_int32)]
 
 
 class RtcInfo(C.Structure):
@@ -95,6 +97,7 @@ def load_library():
         lib.lzani_run_rows_regions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_uint64, C.c_void_p]
         lib.lzani_debug_get_index.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        lib.lzani_debug_sort_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int]
         lib.lzani_row_costs.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.lzani_partition_rows.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.lzani_comm_unique_id.argtypes = [C.c_void_p]
@@ -355,6 +358,14 @@ class Engine:
         o = RtcInfo()
         self._check(self.lib.lzani_get_rtc_info(self.h, C.byref(o)), "lzani_get_rtc_info")
         return {k: getattr(o, k) for k, _ in RtcInfo._fields_ if k != "reserved_"}
+
+    def debug_sort_segments(self, keys, seg_len, n_seg, begin_bit, end_bit):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        assert keys.size == seg_len * n_seg
+        out = np.zeros_like(keys)
+        self._check(self.lib.lzani_debug_sort_segments(self.h, _ptr(keys), _ptr(out), C.c_uint64(seg_len), C.c_uint32(n_seg),
+                                                       C.c_int(begin_bit), C.c_int(end_bit)), "debug_sort_segments")
+        return out
 
     def debug_index(self, gid):
         mrd = self.params["mrd"]

@@ -567,6 +567,55 @@ def test_bacterial_geometry_5mbp(monkeypatch):
     assert got[0, 1, 0] > 4_500_000 and got[3, 4, 0] > 4_000_000 and got[0, 3, 0] < 1_000_000
 
 
+def test_radix_sort_segments_against_numpy():
+    """The engine's own radix sort (lzani_sort.hip) against numpy's stable sort: one segment and many, lengths that are not
+    multiples of a tile, one to eight passes, skewed digits (the all-ones filler of positions without a k-mer), ties kept
+    in input order (stability: equal sort bits, different low bits)."""
+    rng = np.random.default_rng(99)
+    eng = L.Engine()
+    cases = [(1, 1, 0, 64), (5, 3, 0, 8), (8192, 1, 0, 31), (8193, 2, 17, 48), (100_000, 3, 24, 55), (20_001, 7, 0, 64),
+             (1_000_003, 2, 24, 55), (70_000, 1, 32, 56), (3000, 40, 20, 51)]
+    for seg_len, n_seg, b0, b1 in cases:
+        keys = rng.integers(0, 1 << 63, size=seg_len * n_seg, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=seg_len * n_seg, dtype=np.uint64)
+        if seg_len > 1000:
+            keys[rng.random(keys.size) < 0.3] = np.uint64(0xFFFFFFFFFFFFFFFF)            # the filler: one digit holds a third of the keys
+            keys[: seg_len // 2] &= np.uint64((1 << 40) - 1) | np.uint64(0xFFFF000000000000)    # many ties in the middle bits
+        got = eng.debug_sort_segments(keys, seg_len, n_seg, b0, b1)
+        mask = np.uint64(((1 << (b1 - b0)) - 1))
+        for s in range(n_seg):
+            seg = keys[s * seg_len:(s + 1) * seg_len]
+            order = np.argsort((seg >> np.uint64(b0)) & mask, kind="stable")
+            assert np.array_equal(got[s * seg_len:(s + 1) * seg_len], seg[order]), (seg_len, n_seg, b0, b1, s)
+    eng.close()
+
+
+def test_matrix_from_index_and_longest_pair_first_forced(monkeypatch):
+    """The two round-4 pieces of the candidate stage at sizes the oracle covers whole: the presence matrix made from the
+    batch's anchor indexes (k_pm_from_index: every row width, several chunks per slot, groups of less than 128 / 512 slots)
+    and the ticket order of the queues, longest pair first (k_pm_cand's counts -> k_lpt_keys -> sort).  Both forced by the
+    environment; results must equal the default path's and the oracle's."""
+    cases = [(SG.make_set(40, 21, lmin=5000, lmax=9000, fam=5)[1], None),
+             (SG.make_set(150, 22, lmin=2000, lmax=3000, fam=6)[1], None),                 # rw = 8: two words of slots
+             (SG.make_set(24, 23, lmin=60_000, lmax=90_000, fam=4, dmin=0.005, dmax=0.08)[1], dict(mal=13, msl=8, reg=50))]
+    for seqs, prm in cases:
+        want = O.oracle_all2all(seqs, prm, threads=16)
+        eng = L.Engine(prm)
+        eng.set_genomes(seqs)
+        monkeypatch.setenv("LZANI_PM_MIN_ROWS", "1")
+        monkeypatch.setenv("LZANI_PM_FROM_INDEX", "0")
+        base = eng.all2all()
+        assert eng.layout()["bitmap_launches"] == 1 and eng.layout()["matrix_from_index"] == 0 and eng.layout()["lpt_launches"] == 0
+        monkeypatch.setenv("LZANI_PM_FROM_INDEX", "1")
+        monkeypatch.setenv("LZANI_LPT", "1")
+        got = eng.all2all()
+        lay = eng.layout()
+        for k in ("LZANI_PM_MIN_ROWS", "LZANI_PM_FROM_INDEX", "LZANI_LPT"):
+            monkeypatch.delenv(k)
+        eng.close()
+        assert lay["matrix_from_index"] >= 1 and lay["lpt_launches"] == 1, lay
+        assert np.array_equal(base, want) and np.array_equal(got, want), (len(seqs), prm)
+
+
 def test_long_genomes_presence_matrix_natural_trigger():
     """BASELINE configs[3] at its own geometry with enough genomes that the candidate-bitmap form is chosen BY ITSELF (dense
     rows, >= 32 of them: no LZANI_PM_MIN_ROWS): 33 genomes of 4.6-5.2 Mbp in four families, --mal 15 --msl 9 --reg 60 --
@@ -589,6 +638,8 @@ def test_long_genomes_presence_matrix_natural_trigger():
     tm = eng.timing()
     eng.close()
     assert lay["bitmap_launches"] >= 1 and lay["bitmap_launches"] == lay["batches_last_run"] and lay["join_lists"] == 1, lay
+    # (round 4) at this geometry the matrix comes from the batch's indexes and the tickets go longest pair first, by themselves
+    assert lay["matrix_from_index"] >= 1 and lay["lpt_launches"] == lay["bitmap_launches"], lay
     print(f"33 x 5 Mbp: pair kernel {tm['pairs_ms']:.0f} ms, candidate stage {tm['cand_ms']:.0f} ms, index {tm['index_ms']:.0f} ms, k-mer words {tm['kmers_ms']:.0f} ms")
     lens = np.array([len(s) for s in seqs])
     fam = np.array(fam)
@@ -911,6 +962,52 @@ def test_presence_matrix_with_query_lists():
         for q in x:
             assert np.array_equal(out[e], want[r, q]), (r, q)
             e += 1
+
+
+def test_filtered_rows_of_mid_size_genomes_with_long_kmers(monkeypatch):
+    """Filtered rows (query lists a kmer-db filter leaves: the relatives and a few chance hits per row) of mid-size genomes
+    at --mal 15: the tags of such an index do not fit a tag byte, so there are no tag words and the probe form falls back to
+    the rounds of the first kernel.  Since round 4 these rows take the candidate bitmaps from two pairs per query and group
+    on (one matrix row read serves them; the bitmap form of refill reads the bucket whole): bit-exact against the oracle,
+    and timed against the rounds."""
+    import time
+    st = SG.Stream(4404)
+    _, seqs = SG.make_set(24, 5, lmin=280_000, lmax=320_000, fam=4, dmin=0.005, dmax=0.08)
+    n = len(seqs)
+    prm = dict(mal=15, msl=9, reg=60)
+    lists = []
+    for r in range(n):
+        fam = [q for q in range((r // 4) * 4, (r // 4) * 4 + 4) if q != r]
+        extra = []
+        while len(extra) < 3:
+            q = st.randint(0, n - 1)
+            if q != r and q not in fam and q not in extra:
+                extra.append(q)
+        lists.append(sorted(fam + extra))
+    rows = np.arange(n, dtype=np.uint32)
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    qq = np.array([q for x in lists for q in x], np.uint32)
+    if O.lib_ref() is not None:
+        want = O.ref_rows(seqs, rows, off, qq, prm, threads=16)
+    else:
+        want = np.array([O.oracle_pair(seqs[r], seqs[q], prm) for r, x in enumerate(lists) for q in x], dtype=np.int32)
+    eng = L.Engine(prm)
+    eng.set_genomes(seqs)
+    assert eng.layout()["tag_words"] == 0
+    got = eng.run_rows(rows, off, qq).reshape(-1, 3)           # (also makes the k-mer words: not in either timing below)
+    lay = eng.layout()
+    assert lay["bitmap_launches"] == 1, lay
+    assert np.array_equal(got, want.reshape(-1, 3))
+    t = time.perf_counter(); eng.run_rows(rows, off, qq); t_pm = time.perf_counter() - t
+    monkeypatch.setenv("LZANI_PM", "0")
+    t = time.perf_counter(); got0 = eng.run_rows(rows, off, qq).reshape(-1, 3); t_rounds = time.perf_counter() - t
+    assert eng.layout()["bitmap_launches"] == 0
+    monkeypatch.delenv("LZANI_PM")
+    eng.close()
+    assert np.array_equal(got0, want.reshape(-1, 3))
+    print(f"24 x 300 kbp at mal 15, filtered rows of 6 queries: {t_pm * 1e3:.0f} ms with candidate bitmaps, {t_rounds * 1e3:.0f} ms by rounds")
+    assert t_pm * 2 < t_rounds, (t_pm, t_rounds)
 
 
 def test_block_kernel_with_lds_filter(monkeypatch):
