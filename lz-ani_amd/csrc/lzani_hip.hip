@@ -282,7 +282,7 @@ int ensure_slabs(lzani_ctx* c, u32 want_rows)
 
 GenomeTab gtab(const lzani_ctx* c) { return GenomeTab{c->d_t2, c->d_nm, c->d_nmoff, c->d_L, c->d_kmL, c->d_kmS, c->d_hasN}; }
 
-// Join form: the k-mer list of every genome as a query, sorted by (genome, bucket) -- k_join_keys + hipCUB radix sort,
+// Join form: the k-mer list of every genome as a query, sorted by (genome, bucket) -- k_join_keys + the radix sort of lzani_sort.hip,
 // once per run, behind k_kmers (it is part of the path's work like the k-mer words it is made from).
 // the resident part of the join lists (the sorted keys: 8 B per forward position), allocated before the index slabs are
 // sized so that those see what is really left

