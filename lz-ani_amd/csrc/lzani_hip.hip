@@ -544,7 +544,10 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     bool pm = false;
     u64 cb_words = 0;                                        // 32-bit words of one pair's candidate bitmap
     u32 pm_tiles = 0, pm_group = PM_GROUP;
-    const int pm_bits = std::min(c->geo.kb, 30);             // exact up to mal 15: the mixer is a bijection on the key bits
+    // rows of the presence matrix: one per k-mer (exact: the mixer is a bijection on the key bits) where the genomes fill a fair
+    // part of the key space, else the hash's top bits -- 2^9 rows per text position keep the false candidates below 0.2 % of the
+    // query positions, and a group's matrix is cleared and built in proportion to the genomes, not to 4^mal
+    const int pm_bits = std::min(std::min(c->geo.kb, 30), ceil_log2((u64)std::max(c->Tmax, 1)) + 9);
     bool use_join = false;
     std::vector<u32> bstart;
     // Two attempts: the candidate-bitmap form first where it applies; if its buffers (matrix, pair table, bitmaps) cannot be
@@ -581,7 +584,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             for (u32 k = 0; k < n_rows; ++k) max_row = std::max<u64>(max_row, row_off[k + 1] - row_off[k]);
             pm_tiles = (u32)(((u64)Lmax + c->P.mrd + 320 + PM_TILE - 1) / PM_TILE);
             cb_words = (u64)pm_tiles * PM_TILE_WORDS;
-            pm_group = pm_bits <= 24 ? (u32)PM_GROUP : 128u;                      // 64-byte rows up to 2^24 of them, 16-byte rows beyond (16 GB at 2^30)
+            pm_group = pm_bits <= 27 ? (u32)PM_GROUP : 128u;                      // 64-byte rows up to 2^27 of them (8 GB), 16-byte rows beyond (16 GB at 2^30)
             const size_t m_bytes = ((size_t)1 << pm_bits) * (pm_group / 8);
             const size_t x_bytes = query_ids ? ((size_t)c->n * pm_group + 2 * (size_t)c->n + 64) * 4 : 0;   // pair table, query flags, list, count
             const size_t per_pair = (size_t)cb_words * 4;
@@ -800,7 +803,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 pg.G = gtab(c);
                 pg.ref_ids = d_ref + k0; pg.row_off = d_off + k0;
                 pg.slot0 = g0; pg.rows = std::min<u32>(pm_group, rows - g0);
-                pg.M = c->d_pm; pg.rw = ((pg.rows + 127) / 128) * 4; pg.mmask = (u32)lowmask(pm_bits);
+                pg.M = c->d_pm; pg.rw = ((pg.rows + 127) / 128) * 4; pg.mmask = (u32)lowmask(pm_bits); pg.rshift = c->geo.kb - pm_bits;
                 pg.mal = c->P.mal; pg.mrd = c->P.mrd;
                 pg.cbits = c->d_pm_cbits; pg.cb_words = cb_words; pg.e0 = e0; pg.n = c->n; pg.q0 = 0;
                 pg.query_ids = d_q.p; pg.pidx = nullptr; pg.qflag = pg.qlist = pg.qcount = nullptr;

@@ -33,6 +33,10 @@ struct PmArgs {
     u32* M;                   // 2^mbits rows of rw words
     u32 rw;                   // words per matrix row: rows rounded up to 128 slots (16-byte loads)
     u32 mmask;                // 2^mbits - 1
+    int rshift;               // matrix row of a mixed hash h = h >> rshift (its top mbits bits; 0 = the matrix is exact: one row per k-mer).
+                              // A matrix of fewer rows than k-mers (mid-size genomes with long k-mers: 2^30 rows would be cleared and
+                              // written for 2^18 k-mers a slot) answers "maybe" for k-mers that share a row: a candidate bit the pair
+                              // kernel then finds no bucket entry for and drops (refill: dead) -- every reader of a bitmap verifies.
     int mal, mrd;
     u32* cbits;               // candidate bitmaps of the batch's pairs, cb_words 32-bit words each
     u64 cb_words;
@@ -64,7 +68,7 @@ __global__ void __launch_bounds__(256) k_pm_build(PmArgs a, int Tmax)
     const u32 bit = 1u << (s & 31), w = s >> 5;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p + a.mal <= T && p < Tmax; p += gridDim.x * blockDim.x) {
         const u32 h = km[p];
-        if (h != KM_INVALID) atomicOr(&a.M[(u64)(h & a.mmask) * a.rw + w], bit);
+        if (h != KM_INVALID) atomicOr(&a.M[(u64)((h >> a.rshift) & a.mmask) * a.rw + w], bit);
     }
 }
 
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(256) k_pm_cand(PmArgs a)
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint4* src = reinterpret_cast<const uint4*>(a.M + (u64)(h[k] == KM_INVALID ? 0u : (h[k] & a.mmask)) * a.rw);
+        const uint4* src = reinterpret_cast<const uint4*>(a.M + (u64)(h[k] == KM_INVALID ? 0u : ((h[k] >> a.rshift) & a.mmask)) * a.rw);
 #pragma unroll
         for (int j = 0; j < RW4; ++j) row[k][j] = src[j];
     }
