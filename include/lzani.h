@@ -143,6 +143,10 @@ typedef struct lzani_layout_info {
                                              * first (batches of few, long pairs; placement only)                      */
     int32_t  matrix_from_index;             /* presence matrices of the last run made from the batch's anchor indexes
                                              * (long genomes: no global atomics) instead of one atomicOr per text position */
+    int32_t  split_launches;                /* batches of the last run whose pairs were scanned by several waves each (few, long
+                                             * pairs: checkpoints, segments, stitch -- csrc/lzani_kernels_split.h)           */
+    int32_t  reserved_;
+    uint64_t split_segments;                /* segments run for them in all, the ones run again included                    */
 } lzani_layout_info;
 int lzani_get_layout(const lzani_ctx *ctx, lzani_layout_info *info);
 

@@ -646,6 +646,83 @@ template <class W> struct wave_has_mism3<W, std::void_t<decltype(W::HAS_MISM3)>>
 
 template <class W, class = void> struct wave_has_stretch_chain : std::false_type {};
 template <class W> struct wave_has_stretch_chain<W, std::void_t<decltype(W::HAS_STRETCH_CHAIN)>> : std::bool_constant<W::HAS_STRETCH_CHAIN> {};
+// ---- one pair by several waves (long genomes, few pairs: a launch lasts as long as its slowest pair) -----------------------
+// The scan of parse() is sequential, but where it stands after an event -- (i, r_end), lit = 0, tracking -- is all of its
+// state that the EVENTS behind depend on, as long as the region open at that point is later closed by the keep branch (not
+// dropped as short: that branch looks back over the region) -- and an approximate extension ends where its window breaks,
+// wherever it began.  So a query is cut at fixed positions P_1 < P_2 < ..; for every cut a wave scans from P_j with a fresh
+// state through its FIRST event: the state behind it is the cut's CHECKPOINT.  Then segment j runs from checkpoint j
+// (segment 0 from the start) until its state EQUALS a later checkpoint -- the true scan passes through it: the segment
+// stops, the later one has done the rest -- or the query ends; a checkpoint the true scan does not pass through is skipped
+// (its segment's work is void).  What differs between the true scan and a segment started at a checkpoint is bookkeeping:
+// the region open at the checkpoint began earlier in the true scan.  A segment therefore keeps its FIRST region apart
+// (its counts at the start and at its close), and the stitch (split_stitch) puts the true counts together along the chain
+// of segments; a first region that the segment drops, or that the true scan would drop, voids the split (the pair is then
+// scanned whole).  Exact by construction: every hand-over is an equality of states.  (parser.cpp:482-716 has no
+// counterpart: one thread scans one pair.)
+struct SplitStart {                  // where a segment starts: the state behind the first event of a fresh scan from the cut
+    int i, r_end, prev_rs, pre_lit, cl, clit;        // lit = 0, tracking, prev_re = i, nl = 0;  i = -1: no checkpoint (no event behind the cut, or the cut is disabled)
+};
+enum { NO_CHECKPOINT = 0x7FFFFFFF };                 // (as a limit: no checkpoint ahead)
+struct SplitOut {
+    int tm, tl, tc;                  // regions this segment closed, other than its first
+    int first;                       // the first region: 0 still open at the stop, 1 closed by the keep branch, 2 dropped (void), 3 segment 0 (none apart)
+    int first_cl, first_clit;        // first = 1: its counts at the close (with what the segment started from)
+    int first_re;                    //            the query position it ended at (prev_re at the close): the stitch tests the true span
+    int stop;                        // the checkpoint the segment stopped at (index of the cut), -1 = the end of the query
+    int open_cl, open_clit, open_rs; // at the stop: the open region's counts and start (if first = 0: the first region's, as the segment sees them)
+    // How far back a distant match may look (try_extend_backward's bound, parser.cpp:636-660) is i - FLOOR: the floor is the end
+    // of the last region the scan KEPT (a dropped region leaves it where it was: prev_rs - pre_lit).  A segment knows the true
+    // floor from its first keep on; before, its own (the cut) is an upper bound of the true one, so its look-back is a lower
+    // bound -- good as long as every backward scan breaks inside it (else first = 2).
+    int assumed;                     // at the close of the first region the segment went on as if the true scan 1 kept / 2 dropped it (0: not closed)
+    int first_floor;                 // assumed = 2: the segment's floor then (the stitch wants the true floor at or below it)
+    int synced, floor;               // at the stop: the segment's floor is the true one (it kept a region) / its value
+};
+// the stitch of one pair: seg[0 .. n) in cut order, starts[j] = the checkpoint of cut j (j >= 1); false = void (scan the pair whole)
+// void_at / void_from (optional): the segment whose work is void and the one that handed over to it -- run that one again with
+// the void one's cut disabled and the stitch may get through (void_at = -1: nothing to retry)
+LZ_HD bool split_stitch(const SplitStart* starts, const SplitOut* seg, int n, int reg, int out[3], int* void_at = nullptr, int* void_from = nullptr)
+{
+    int from = -1;
+    if (void_at) { *void_at = -1; *void_from = -1; }
+#define LZ_SPLIT_VOID(at) do { if (void_at) { *void_at = (at); *void_from = from; } return false; } while (0)
+    int tm = 0, tl = 0, tc = 0;
+    int open_cl = 0, open_clit = 0, open_rs = -1;          // the TRUE open region at the current segment's start
+    int floor = 0;                                         // the TRUE floor there
+    int j = 0;
+    for (int guard = 0; guard <= n; ++guard) {
+        const SplitOut& o = seg[j];
+        if (o.first == 2) LZ_SPLIT_VOID(j > 0 ? j : -1);
+        int t_cl = o.open_cl, t_clit = o.open_clit, t_rs = o.open_rs;      // the true open region at the segment's stop
+        if (j > 0) {
+            const SplitStart& st = starts[j];
+            if (o.first == 1) {                            // the first region closed inside: its true counts, the keep test on the true span
+                const int cl = open_cl - st.cl + o.first_cl, clit = open_clit - st.clit + o.first_clit;
+                const bool dropped = open_rs >= 0 && o.first_re - open_rs < reg;       // by the true scan: its start is the true one
+                if (o.assumed == 1 && dropped) LZ_SPLIT_VOID(j);       // the segment went on as if it were kept
+                if (o.assumed == 2 && (!dropped || floor > o.first_floor)) LZ_SPLIT_VOID(j);   // ... dropped, looking back to its own floor
+                if (!dropped && cl && cl + clit >= reg) { tm += cl; tl += clit; ++tc; }
+            } else {                                       // still open at the stop: the true region goes on
+                t_cl = open_cl - st.cl + o.open_cl; t_clit = open_clit - st.clit + o.open_clit; t_rs = open_rs;
+            }
+        }
+        tm += o.tm; tl += o.tl; tc += o.tc;
+        if (o.stop < 0) {                                  // the end of the query: calc_stats closes what is open
+            if (j > 0 && o.first == 0) { if (t_cl && t_cl + t_clit >= reg) { tm += t_cl; tl += t_clit; ++tc; } }
+            out[0] = tm; out[1] = tl; out[2] = tc;
+            return true;
+        }
+        if (o.stop <= j || o.stop >= n) LZ_SPLIT_VOID(-1);
+        if (o.synced) floor = o.floor;
+        from = j;
+        open_cl = t_cl; open_clit = t_clit; open_rs = t_rs;
+        j = o.stop;
+    }
+    LZ_SPLIT_VOID(-1);
+#undef LZ_SPLIT_VOID
+}
+
 template <class W, bool ALN = false>
 struct PairMachine {
     W& w;
@@ -741,11 +818,14 @@ struct PairMachine {
     }
 
     // try_extend_backward (parser.cpp:412-441)
-    LZ_HD int extend_backward(int q0, int r0, int max_len, bool have0 = false, u64 B0 = 0)
+    // bounded: set when the scan ended at the look-back bound max_len (no break before it, and the texts go on behind it) -- with a
+    // larger bound the result might be another one (the split's segments look back over a lower bound of what the true scan may)
+    LZ_HD int extend_backward(int q0, int r0, int max_len, bool have0 = false, u64 B0 = 0, bool* bounded = nullptr)
     {
         int maxlen = imin(max_len, imin(q0, r0));
         int last = 0;
         u64 prevB = 0;
+        bool broke = false;
         for (int base = 0; base < maxlen; base += 64) {
             int n = imin(64, maxlen - base);
             u64 B = (have0 && base == 0) ? B0 : w.mism_bwd(q0 - base, r0 - base, n);
@@ -753,9 +833,10 @@ struct PairMachine {
             u64 qm = m.qual;
             if (m.brk) qm &= lowmask(ctz64(m.brk) + 1);
             if (qm) last = base + (63 - clz64(qm)) + 1;
-            if (m.brk) break;
+            if (m.brk) { broke = true; break; }
             prevB = B;
         }
+        if (bounded) *bounded = !broke && max_len < imin(q0, r0);
         return last;
     }
 
@@ -798,20 +879,72 @@ struct PairMachine {
         g.seg(F, len);
     }
 
-    LZ_HD void run(int out[3])
+    LZ_HD void run(int out[3]) { run_impl<0>(out, 0, nullptr, nullptr, 0, 0, nullptr, nullptr); }
+    // one segment of a split pair (see SplitStart): from checkpoint `start` (nullptr: the start of the query) to the first
+    // later checkpoint the scan passes through (cuts seg + 1 .. n_cuts - 1), or to the end of the query
+    LZ_HD void run_segment(int seg, const SplitStart* start, const SplitStart* cuts, int n_cuts, SplitOut* so)
+    { int dummy[3]; run_impl<2>(dummy, seg, start, cuts, n_cuts, 0, so, nullptr); }
+    // the checkpoint of a cut at query position p0: a fresh scan from there through its first event
+    LZ_HD void run_checkpoint(int p0, SplitStart* cp)
+    { int dummy[3]; run_impl<1>(dummy, 0, nullptr, nullptr, 0, p0, nullptr, cp); }
+
+    // SPLIT: 0 = the whole pair; 1 = a checkpoint; 2 = a segment
+    template <int SPLIT>
+    LZ_HD void run_impl(int out[3], int seg, const SplitStart* start, const SplitStart* cuts, int n_cuts, int p0, SplitOut* so, SplitStart* cp)
     {
         int i = 0, lit = 0, r_end = 0;
         bool trk = false;
         int prev_rs = -1, prev_re = 0, pre_lit = 0;
         const int iend = D - P.msl;              // loop condition i + msl < |Q| (quirk Q10)
         int rounds = 0;                          // every round advances i by >= 1: hard exit bound
+        [[maybe_unused]] bool first_open = false;         // SPLIT 2: the region the segment started in is still open
+        [[maybe_unused]] bool tainted = false;            //          how far back a distant match may look is known as a lower bound only
+        [[maybe_unused]] int next_cut = 0, events = 0, lim_i = -1;
+        if constexpr (SPLIT == 1) { i = p0; cp->i = -1; cp->r_end = cp->prev_rs = cp->pre_lit = cp->cl = cp->clit = 0; }
+        if constexpr (SPLIT == 2) {
+            so->tm = so->tl = so->tc = 0; so->first = 3; so->first_cl = so->first_clit = so->first_re = 0;
+            so->stop = -1; so->open_cl = so->open_clit = 0; so->open_rs = -1;
+            so->assumed = 0; so->first_floor = 0; so->synced = 1; so->floor = 0;
+            next_cut = seg + 1;
+            if (start) {
+                // (w.uniform: a value out of memory, the same in every lane -- the device's policy says so to the compiler)
+                i = w.uniform(start->i); r_end = w.uniform(start->r_end); trk = true; prev_rs = w.uniform(start->prev_rs); prev_re = i;
+                pre_lit = w.uniform(start->pre_lit);
+                g.cl = w.uniform(start->cl); g.clit = w.uniform(start->clit);
+                first_open = true; tainted = true; so->first = 0;
+            }
+        }
 
         while (i < iend) {
             if (++rounds > D + 8) { LZ_GUARD_TRIP(3); out[0] = -1; out[1] = i; out[2] = lit; return; }
+            if constexpr (SPLIT == 1) {
+                if (events) {                    // the state behind the first event: the checkpoint (an event leaves lit = 0, tracking)
+                    cp->i = i; cp->r_end = r_end; cp->prev_rs = prev_rs; cp->pre_lit = pre_lit; cp->cl = g.cl; cp->clit = g.clit;
+                    return;
+                }
+            }
+            if constexpr (SPLIT == 2) {
+                if (i >= lim_i) {                // (i only grows) at or beyond the nearest checkpoint ahead: look at the next few cuts
+                    while (next_cut < n_cuts && i > w.uniform(cuts[next_cut].i)) ++next_cut;       // (passed: not on the scan's way)
+                    lim_i = NO_CHECKPOINT;
+                    for (int k = next_cut; k < n_cuts && k < next_cut + 4; ++k) {           // (a long extension may carry a cut's checkpoint beyond the next cut's)
+                        const int ci = w.uniform(cuts[k].i);
+                        if (ci == i && trk && lit == 0 && w.uniform(cuts[k].r_end) == r_end) {         // behind an event, in the checkpoint's very state: hand over
+                            so->tm = g.tm; so->tl = g.tl; so->tc = g.tc;
+                            so->stop = k; so->open_cl = g.cl; so->open_clit = g.clit; so->open_rs = prev_rs;
+                            so->synced = !tainted; so->floor = prev_rs - pre_lit;
+                            return;
+                        }
+                        if (ci > i) lim_i = imin(lim_i, ci);
+                    }
+                    w.split_limit(lim_i);        // (the policy's hand-written loops commit several events a call: none across a checkpoint)
+                }
+            }
             int adv = 0, bpos = 0, blen = 0;
             w.stamp(1);
             int in_hand = 0;
-            if constexpr (wave_has_null_chain<W>::value && !ALN) {
+            if constexpr (wave_has_null_chain<W>::value && !ALN && SPLIT != 1) {
+                if (!(SPLIT == 2 && (first_open || tainted)))     // (the chain closes regions and looks back by itself: not while the first region is apart)
                 // Straight after an event (tracking, nothing skipped yet) the policy may run the whole cycle
                 // "tracking round without a seed candidate -> next plain candidate -> distant null event over a dropped
                 // short region" for as many events as it lasts: exactly the updates of the null event below, nothing
@@ -832,7 +965,7 @@ struct PairMachine {
             w.stamp(4);
             int sc_kind = 0;
             bool sc_hit = false;
-            if constexpr (wave_has_stretch_chain<W>::value && !ALN) {
+            if constexpr (wave_has_stretch_chain<W>::value && !ALN && SPLIT != 1) {
                 // a run of close matches behind each other, by the hand-scheduled stretch chain: the events it takes are
                 // committed inside (the open region's accumulators, nl = 0 throughout); what ends the run comes back half
                 // done -- an extension that runs on, an anchor before the first seed step, a round without a seed
@@ -868,6 +1001,7 @@ struct PairMachine {
                 if (lit > P.mqd) trk = false;
                 continue;
             }
+            if constexpr (SPLIT == 1) events = 1;
 #if defined(LZANI_EXP) && LZANI_EXP >= 1                     // diagnostic build: events found but not processed
             i += blen; r_end = bpos + blen; lit = 0; trk = true; prev_re = i;
             continue;
@@ -888,7 +1022,21 @@ struct PairMachine {
             } else {
                 // distant match (parser.cpp:636-685)
                 int avail;
-                if (__builtin_expect(prev_rs >= 0 && prev_re - prev_rs < P.reg, 1)) {       // drop the short region
+                // (a segment of a split pair: its FIRST region began elsewhere in the true scan, so its counts go aside for the stitch,
+                // and whether the true scan keeps or drops it is the stitch's to say: the segment goes on by its own view of the
+                // region's span and says which way it went -- see SplitOut)
+                [[maybe_unused]] bool sure = true;         // SPLIT 2: `avail` is the true scan's, not a lower bound of it
+                const bool drop = prev_rs >= 0 && prev_re - prev_rs < P.reg;
+                if constexpr (SPLIT == 2) {
+                    if (first_open) {
+                        first_open = false;
+                        so->first = 1; so->first_cl = g.cl; so->first_clit = g.clit; so->first_re = prev_re;
+                        g.discard();
+                        if (drop) { so->assumed = 2; so->first_floor = prev_rs - pre_lit; sure = false; }
+                        else { so->assumed = 1; tainted = false; }
+                    } else if (tainted) { if (drop) sure = false; else tainted = false; }
+                }
+                if (__builtin_expect(drop, 1)) {          // drop the short region
                     avail = pre_lit + (i - prev_rs);
                     g.discard();
                     if (ALN) c.clear();
@@ -899,7 +1047,7 @@ struct PairMachine {
                 // The candidate's record may prove, without touching the texts, that an approximate extension does not
                 // move (a chance k-mer with random flanks: four extensions out of five of an unrelated pair).
                 u32 rec = EXT_REC_NONE;
-                const bool have_rec = !ALN && w.ext_record(rec);
+                const bool have_rec = !ALN && !(SPLIT == 2 && !sure) && w.ext_record(rec);      // (a record speaks for ONE look-back bound)
                 const bool null_f = have_rec && (rec & EXT_REC_NULLF);
                 // (aw <= 15) the forward extension itself may be in the record: then neither side of it needs the texts
                 const bool fwd_k = have_rec && P.aw <= 15 && (rec & EXT_REC_FWDK);
@@ -920,6 +1068,7 @@ struct PairMachine {
                     continue;
                 }
                 int b = 0;
+                [[maybe_unused]] bool bounded = SPLIT == 2 && nb == 0 && imin(i, bpos) > 0;     // (no look-back at all where the true scan may have one)
                 if (bwd_free | fwd_free) {
                     // one side is known (empty, or the extension itself from the record): fetch and scan the other one only
                     if (!bwd_free) { Bb = w.mism_bwd(i, bpos, nb); b = extend_backward(i, bpos, avail, true, Bb); }
@@ -930,8 +1079,12 @@ struct PairMachine {
                     const int nf = imax(0, imin(64, imin(D - fq, T - fr)));
                     w.mism2(fq, fr, 1, nf, i - 1, bpos - 1, -1, nb, Bf, Bb);
                     haveF = true;
+                    if constexpr (SPLIT == 2) {
+                        if (nb > 0) b = extend_backward(i, bpos, avail, true, Bb, &bounded);
+                    } else
                     b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;
                 }
+                if constexpr (SPLIT == 2) { if (!sure && bounded) { so->first = 2; return; } }      // the lower bound cut the scan short: void
                 g.finalize();                                           // a match_distant factor follows
                 region_close();
                 if (__builtin_expect(b > 0, 0)) {
@@ -968,8 +1121,18 @@ struct PairMachine {
             prev_re = i;
         }
         w.stamp(6);
+        if constexpr (SPLIT == 1) return;          // (no event behind the cut: no checkpoint)
         if (trk)   // tail compare against r_end - msl (parser.cpp:713, quirk Q3)
             seg_range(i - lit, r_end - P.msl, lit + (D - i));
+        if constexpr (SPLIT == 2) {
+            if (first_open) {                      // the first region is open to the end: the stitch closes it with the true counts
+                so->open_cl = g.cl; so->open_clit = g.clit; so->open_rs = prev_rs;
+                g.discard();
+            }
+            g.finalize();
+            so->tm = g.tm; so->tl = g.tl; so->tc = g.tc; so->stop = -1;
+            return;
+        }
         g.finalize();
         region_close();
         out[0] = g.tm; out[1] = g.tl; out[2] = g.tc;

@@ -43,6 +43,7 @@ int lzani_sort_keys(const unsigned long long* in, unsigned long long* out, size_
 #include "lzani_kernels_index.h"
 #include "lzani_kernels_cand.h"
 #include "lzani_kernels_pairs.h"
+#include "lzani_kernels_split.h"
 #include "lzani_rtc.h"
 
 // ============================================================================================
@@ -125,6 +126,8 @@ struct lzani_ctx {
     size_t lpt_pairs = 0;
     int lpt_launches = 0;         // pair-kernel launches of the last run that took their tickets longest pair first
     int pmfi_launches = 0;        // presence matrices of the last run made by k_pm_from_index
+    int split_launches = 0;       // batches of the last run whose pairs were scanned by several waves each
+    u64 split_items = 0;          // ... segments run in all (with the ones run again)
     bool pm_attr_set = false;
     u32 pmfi_attr_set = 0;                // k_pm_from_index<RW>: bit RW = its LDS limit is raised
 
@@ -508,6 +511,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
     c->pm_launches = 0;
     c->lpt_launches = 0;
     c->pmfi_launches = 0;
+    c->split_launches = 0;
+    c->split_items = 0;
     c->rtc_launches = 0;
     if (n_rows == 0) return LZANI_OK;
     const u64 n_pairs = row_off[n_rows];
@@ -780,8 +785,27 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         HIPCHK(c, hipEventRecord(ev[1], c->stream));
         // Few, long pairs (the batch leaves a wave slot only a few of them): the launch is over when its slowest pair is, so
         // the pairs with the most candidates -- the related ones -- go first (k_pm_cand counts, k_lpt_keys + a sort order)
+        // ... and fewer pairs than half the wave slots: every pair by several waves, segment by segment (lzani_kernels_split.h)
+        u32 split_S = 0;
+        int split_seglen = 0;
+        if (pm && !rs && e1 > e0 && c->P.mqd + c->P.mrd <= 128) {
+            const char* se = getenv("LZANI_SPLIT");
+            const char* sl = getenv("LZANI_SPLIT_SEGLEN");
+            const u64 bp = e1 - e0, slots = (u64)max_blocks * 4;
+            int Lmax = 0;
+            for (u32 g = 0; g < c->n; ++g) Lmax = std::max(Lmax, c->L[g]);
+            const int Dmax = Lmax + c->P.mrd;
+            const bool on = se ? *se == '1' : (cb_words >= 8192 && bp * 2 <= slots);
+            if (on && bp * 2 <= 0xFFFFFFFFull / 64) {
+                u32 S = (u32)std::min<u64>(16, std::max<u64>(2, slots / bp));
+                int seglen = (Dmax + (int)S - 1) / (int)S;
+                if (sl && atoi(sl) > 0) { seglen = atoi(sl); S = (u32)std::min<int>(64, std::max(2, (Dmax + seglen - 1) / seglen)); }
+                seglen = std::max(seglen, 512);
+                if ((Dmax + seglen - 1) / seglen >= 2) { split_S = std::min<u32>(S, (u32)((Dmax + seglen - 1) / seglen)); split_seglen = seglen; }
+            }
+        }
         bool lpt = false;
-        if (pm && e1 > e0) {
+        if (pm && e1 > e0 && split_S < 2) {
             const char* le = getenv("LZANI_LPT");
             const u64 bp = e1 - e0;
             lpt = !rs && bp >= 2 && bp <= (u64)max_blocks * 4 * 32 && (le ? *le == '1' : cb_words >= 8192);     // (queries from ~256 kbp on)
@@ -957,7 +981,61 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 else if (tw) LZ_PAIRS(true, false, false, true, true);
                 else LZ_PAIRS(true, false, false, true, false);
             } else if (!fast) LZ_PAIRS(false, false, false, false, false);
-            else if (pm) {                              // dense rows: candidate bitmaps made ahead (k_pm_cand)
+            else if (pm && split_S >= 2) {               // few, long pairs: several waves a pair (lzani_kernels_split.h)
+                c->pm_launches += 1;
+                c->split_launches += 1;
+                const u32 npb = (u32)(e1 - e0), S = split_S;
+                DevBuf<SplitStart> d_cuts;
+                DevBuf<SplitOut> d_souts;
+                DevBuf<u32> d_work, d_next, d_cnt;
+                DevBuf<unsigned char> d_done;
+                HIPCHK(c, d_cuts.alloc((size_t)npb * S));
+                HIPCHK(c, d_souts.alloc((size_t)npb * S));
+                HIPCHK(c, d_work.alloc((size_t)npb * S));
+                HIPCHK(c, d_next.alloc((size_t)npb * S));
+                HIPCHK(c, d_cnt.alloc(4));
+                HIPCHK(c, d_done.alloc(npb));
+                HIPCHK(c, hipMemsetAsync(d_cnt.p, 0, 16, c->stream));
+                HIPCHK(c, hipMemsetAsync(d_done.p, 0, npb, c->stream));
+                HIPCHK(c, hipMemsetAsync(d_cuts.p, 0xFF, (size_t)npb * S * sizeof(SplitStart), c->stream));      // (cut 0 of every pair: no checkpoint)
+                SplitArgs sa;
+                sa.pa = pa; sa.rows = rows; sa.n_pairs = npb; sa.S = S; sa.seglen = split_seglen;
+                sa.cuts = d_cuts.p; sa.outs = d_souts.p; sa.work = d_work.p; sa.work_next = d_next.p; sa.counters = d_cnt.p; sa.done = d_done.p;
+                sa.reg = c->P.reg; sa.last_round = 0;
+                const int dsel = defp ? 1 : lgp ? 2 : 0;
+                auto launch = [&](int mode, u32 items) {
+                    const dim3 gs((u32)std::min<u64>(((u64)items + 3) / 4, max_blocks)), bs4(256);
+                    sa.n_work = items;
+#define LZ_SPLIT(N, D) do { if (mode == 0) hipLaunchKernelGGL((k_split<N, D, 0>), gs, bs4, 0, c->stream, sa); else hipLaunchKernelGGL((k_split<N, D, 1>), gs, bs4, 0, c->stream, sa); } while (0)
+                    if (nf) { if (dsel == 1) LZ_SPLIT(true, 1); else if (dsel == 2) LZ_SPLIT(true, 2); else LZ_SPLIT(true, 0); }
+                    else { if (dsel == 1) LZ_SPLIT(false, 1); else if (dsel == 2) LZ_SPLIT(false, 2); else LZ_SPLIT(false, 0); }
+#undef LZ_SPLIT
+                };
+                launch(0, npb * (S - 1));                                  // the checkpoints
+                {
+                    std::vector<u32> all((size_t)npb * S);
+                    for (size_t k = 0; k < all.size(); ++k) all[k] = (u32)k;
+                    HIPCHK(c, hipMemcpyAsync(d_work.p, all.data(), all.size() * 4, hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));            // (`all` leaves scope)
+                }
+                u32 items = npb * S;
+                u32* cur = d_work.p; u32* nxt = d_next.p;
+                for (int round = 0; round < 12 && items; ++round) {
+                    HIPCHK(c, hipMemsetAsync(d_cnt.p, 0, 8, c->stream));     // tickets, next round's items (the finished pairs' count stays)
+                    sa.work = cur; sa.work_next = nxt;
+                    launch(1, items);
+                    sa.last_round = round >= 6;
+                    hipLaunchKernelGGL(k_split_stitch, dim3((npb + 255) / 256), dim3(256), 0, c->stream, sa);
+                    u32 cnt[4] = {0, 0, 0, 0};
+                    HIPCHK(c, hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    c->split_items += items;
+                    items = cnt[1];
+                    std::swap(cur, nxt);
+                    if (items == 0 && cnt[2] != npb) return fail(c, LZANI_ERR_DEVICE, "split pairs: the stitch left pairs behind");
+                }
+                if (items) return fail(c, LZANI_ERR_DEVICE, "split pairs: no end of rounds");
+            } else if (pm) {                            // dense rows: candidate bitmaps made ahead (k_pm_cand)
                 c->pm_launches += 1;
                 if (rtc_launch()) {}
                 else if (nf && defp) LZ_PAIRS_PM(true, 1);
@@ -1333,6 +1411,7 @@ int lzani_get_layout(const lzani_ctx* c, lzani_layout_info* o)
     o->bytes_genomes = c->total_nm * (16 + 8) + (c->d_kmL ? c->total_nm * 64 * 8 : 0);
     o->join_lists = c->join_mode; o->block_launches = c->blk_launches; o->bitmap_launches = c->pm_launches; o->rtc_launches = c->rtc_launches;
     o->lpt_launches = c->lpt_launches; o->matrix_from_index = c->pmfi_launches;
+    o->split_launches = c->split_launches; o->split_segments = c->split_items;
     return LZANI_OK;
 }
 

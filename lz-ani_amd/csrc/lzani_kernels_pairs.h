@@ -71,7 +71,9 @@ template <int CHAIN> struct ChainP {
 #ifndef LZANI_STRETCH_DENSE
 #define LZANI_STRETCH_DENSE 0
 #endif
-template <bool FAST, bool BK = false, bool JOIN = false, int CHAIN = 0, bool LFLT = false>
+// SPLITW: the wave scans one SEGMENT of a pair (lzani_core.h: SplitStart; lzani_kernels_split.h): its hand-written loops
+// commit several events a call, none of them across the next checkpoint (split_limit)
+template <bool FAST, bool BK = false, bool JOIN = false, int CHAIN = 0, bool LFLT = false, bool SPLITW = false>
 struct DevWave {
     static constexpr bool NULL_CHAIN = CHAIN != 0;      // (see ChainP)
     const Params& P;
@@ -92,6 +94,10 @@ struct DevWave {
     int iend = 0;    // steps exist for query positions < iend
     int scan_pos = 0, q_head = 0, q_cnt = 0;
     int last_src = -1;   // queue entry the event just returned came from, if its null-extension record applies
+    int stop_i = 0x7FFFFFFF;     // SPLITW: the query position of the nearest checkpoint ahead
+    __device__ __forceinline__ void split_limit(int at) { stop_i = at; }
+    static __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    enum { SPLIT_MARGIN = 256 };  // a chain call's last commit starts below the limit and moves less than this (gap <= mqd, match < 72 + a first extension chunk)
     u32 a_ext = EXT_REC_NONE;    // lane k: null-extension record of candidate k (lzani_core.h: null_ext_record)
     // Join form of candidate detection (long genomes): the wave's candidate bitmap over the query positions of the
     // pair, filled by join() before the scan; nullptr = candidates are probed position by position (refill)
@@ -720,7 +726,9 @@ struct DevWave {
         // (N-free pair: the rounds of the fast turns -- the ones a GO bit lets through -- only ever see real msl-mers: all 64
         // query lanes, all 80 window positions inside one strand; their address arithmetic then needs no clamp, LZ_NC_WORD7N)
         constexpr bool nf = CP::NF;                 // (a kernel for genomes without N)
-        const int ilim = imin(imin(scan_pos, iend) - NT, nf ? Q.L - MSL + 1 - 64 : iend), rlim = R.len - MSL + 1 - WIN;
+        int ilim = imin(imin(scan_pos, iend) - NT, nf ? Q.L - MSL + 1 - 64 : iend);
+        const int rlim = R.len - MSL + 1 - WIN;
+        if constexpr (SPLITW) ilim = imin(ilim, stop_i - (int)SPLIT_MARGIN);
         const int len = a_len;
         const bool plain = len > 0;
         const u32 rec = a_ext;
@@ -742,7 +750,8 @@ struct DevWave {
         }
         const int gap = s_pos - end;
         const bool distant = (gap > MQD) | (iabs((s_u & 0x7FFFFFFF) - (rend + gap)) > MRD);
-        const bool go = pred & (succ < q_cnt) & (s_u < 0) & distant;
+        bool go = pred & (succ < q_cnt) & (s_u < 0) & distant;
+        if constexpr (SPLITW) go &= s_pos <= ilim;              // (a fast turn commits the successor: it, too, below the limit)
         a_len = (len & 0xFF) | (succ << 8) | (go ? 0x8000 : 0) | (cap ? 0x10000 : 0) | ((t2 & 0xFF) << 17);      // (t2 <= 127 + 31)
     }
     __device__ __forceinline__ bool ext_record(u32& x) const
@@ -863,7 +872,8 @@ struct DevWave {
         typedef ChainP<CHAIN> CP;                              // params.h:34-48, or the set this kernel was compiled for
         enum { MQD = CP::MQD, MRD = CP::MRD, MSL = CP::MSL, REG = CP::REG, AW = CP::AW, AM = CP::AM, AR = CP::AR, NT = CP::NT, WIN = CP::WIN };
         static_assert(!CHAIN || chain_params_ok(CP::P), "the null chain is not written for these parameters");
-        const int ilim = imin(scan_pos, iend) - NT;             // the queue and the query cover the tracking steps of i <= ilim
+        const int ilim_q = imin(scan_pos, iend) - NT;           // the queue and the query cover the tracking steps of i <= ilim
+        const int ilim = SPLITW ? imin(ilim_q, stop_i - (int)SPLIT_MARGIN) : ilim_q;
         const int rlim = R.len - MSL + 1 - WIN;                 // the seed window of r_end <= rlim is complete
         const u32 ldsb = (u32)(size_t)bitmap;                   // LDS byte offset (low half of the flat address)
         const u32 zero = 0, one = 1;
@@ -872,13 +882,17 @@ struct DevWave {
         int code, ap, rec, t0, t1, t2, kb, kc, qh = q_head;
         u64 m, seed;
 #if defined(LZANI_STAMPS) || defined(LZANI_PATH_STATS)    // (diagnostic builds: the bookkeeping makes the compiler lose sight of the uniformity)
-        i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end); qh = __builtin_amdgcn_readfirstlane(qh);
-        prev_rs = __builtin_amdgcn_readfirstlane(prev_rs); prev_re = __builtin_amdgcn_readfirstlane(prev_re);
-        pre_lit = __builtin_amdgcn_readfirstlane(pre_lit);
-        const int qc_u = __builtin_amdgcn_readfirstlane(q_cnt), ilim_u = __builtin_amdgcn_readfirstlane(ilim), rlim_u = __builtin_amdgcn_readfirstlane(rlim);
+        constexpr bool unify = true;
 #else
-        const int qc_u = q_cnt, ilim_u = ilim, rlim_u = rlim;
+        constexpr bool unify = SPLITW;                    // (a segment's state comes out of memory)
 #endif
+        int qc_u = q_cnt, ilim_u = ilim, rlim_u = rlim;
+        if constexpr (unify) {
+            i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end); qh = __builtin_amdgcn_readfirstlane(qh);
+            prev_rs = __builtin_amdgcn_readfirstlane(prev_rs); prev_re = __builtin_amdgcn_readfirstlane(prev_re);
+            pre_lit = __builtin_amdgcn_readfirstlane(pre_lit);
+            qc_u = __builtin_amdgcn_readfirstlane(q_cnt); ilim_u = __builtin_amdgcn_readfirstlane(ilim); rlim_u = __builtin_amdgcn_readfirstlane(rlim);
+        }
         u32 rk0, rk1, qk, a0, a1, aq, t, bq, w1, dumv, qkb, rk0b, rk1b;
 #ifdef LZANI_CHAIN_STATS
         int ncnt = 0;
@@ -1016,7 +1030,13 @@ struct DevWave {
 #define LZ_NC_PRIO_ON
 #define LZ_NC_PRIO_OFF
 #endif
-#define LZ_NC_ASM(WORD, WORDF) \
+        /* (a segment of a split pair: the queued candidate itself must lie below the limit -- a lost-mode jump to it may be long) */
+#define LZ_NC_SPLITCHK \
+            "v_readlane_b32 %[t0], %[apos], %[qh]\n\t" \
+            "s_cmp_gt_i32 %[t0], %[ilim]\n\t" \
+            "s_cbranch_scc1 Lnc_end_%=\n\t"
+#define LZ_NC_ASM(WORD, WORDF) LZ_NC_ASM_X(WORD, WORDF, "")
+#define LZ_NC_ASM_X(WORD, WORDF, SPLCHK) \
         asm volatile( \
             LZ_NC_PRIO_ON \
             "s_mov_b32 %[code], 0\n\t" \
@@ -1052,6 +1072,7 @@ struct DevWave {
             "s_cbranch_scc1 Lnc_end_%=\n\t" \
             "s_cmp_gt_i32 %[rend], %[rlim]\n\t" \
             "s_cbranch_scc1 Lnc_end_%=\n\t" \
+            SPLCHK \
             LZ_NC_LOADS_F \
             /* While the loads fly: the next queued candidate and, should the round find no seed candidate, whether it is */ \
             /* a null event (t2 = 1): plain, distant, the open region short (dropped), both extensions empty by the record */ \
@@ -1553,6 +1574,12 @@ struct DevWave {
 #ifdef LZANI_PHASE_TIME
         const unsigned long long pt_t0 = pt_now();
 #endif
+        if constexpr (SPLITW) {
+            if constexpr (MSL == 9) { LZ_NC_ASM_X(LZ_NC_WORD9, LZ_NC_WORD9, LZ_NC_SPLITCHK) }
+            else if constexpr (MSL == 8) { LZ_NC_ASM_X(LZ_NC_WORD8, LZ_NC_WORD8, LZ_NC_SPLITCHK) }
+            else if constexpr (CP::NF) { LZ_NC_ASM_X(LZ_NC_WORD7, LZ_NC_WORD7N, LZ_NC_SPLITCHK) }
+            else { LZ_NC_ASM_X(LZ_NC_WORD7, LZ_NC_WORD7, LZ_NC_SPLITCHK) }
+        } else
         if constexpr (MSL == 9) { LZ_NC_ASM(LZ_NC_WORD9, LZ_NC_WORD9) }
         else if constexpr (MSL == 8) { LZ_NC_ASM(LZ_NC_WORD8, LZ_NC_WORD8) }
         else if constexpr (CP::NF) { LZ_NC_ASM(LZ_NC_WORD7, LZ_NC_WORD7N) }          // (N-free by instantiation: see chain_classes)
@@ -1566,7 +1593,7 @@ struct DevWave {
             // bitmap has more: refill first and come back -- the round is then this loop's, not the compiler's, and a
             // queue tail costs no wave-wide detection of its own (find_event's light round stays for the scan that
             // has jumped over the queue: related stretches).
-            if (code == 0 && scan_pos >= i && scan_pos < iend && (qh >= q_cnt || (i > ilim && restart_at != i))) refill_only = true;
+            if (code == 0 && scan_pos >= i && scan_pos < iend && (qh >= q_cnt || (i > ilim_q && restart_at != i))) refill_only = true;
         }
         pre_round = code == 1;
         if (code == 0) LZ_PS(16); else if (code == 1) LZ_PS(17); else if (code == 2) LZ_PS(18); else LZ_PS(19);
@@ -1616,7 +1643,7 @@ struct DevWave {
     {
         typedef ChainP<CHAIN> CP;
         enum { MQD = CP::MQD, MRD = CP::MRD, MSL = CP::MSL, AW = CP::AW, AM = CP::AM, AR = CP::AR, NT = CP::NT, WIN = CP::WIN };
-        const int ilim = iend - NT, rlim = R.len - MSL + 1 - WIN;
+        const int ilim = SPLITW ? imin(iend - NT, stop_i - (int)SPLIT_MARGIN) : iend - NT, rlim = R.len - MSL + 1 - WIN;
         const u32 ldsb = (u32)(size_t)bitmap;
         const u32 zero = 0, one = 1;
         const u32* const qks = uniform_ptr(qkS);
@@ -1636,12 +1663,16 @@ struct DevWave {
         [[maybe_unused]] u32 e0, e1, e2, e3, tagl;         //              the seed step's bucket, its tag
         [[maybe_unused]] const unsigned long long* const cbp = JOIN ? reinterpret_cast<const unsigned long long*>(uniform_ptr(reinterpret_cast<const u32*>(cand_bits))) : nullptr;
 #if defined(LZANI_STAMPS) || defined(LZANI_PATH_STATS)
-        i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end);
-        cl = __builtin_amdgcn_readfirstlane(cl); clit = __builtin_amdgcn_readfirstlane(clit);
-        const int ilim_u = __builtin_amdgcn_readfirstlane(ilim), rlim_u = __builtin_amdgcn_readfirstlane(rlim);
+        constexpr bool unify = true;
 #else
-        const int ilim_u = ilim, rlim_u = rlim;
+        constexpr bool unify = SPLITW;
 #endif
+        int ilim_u = ilim, rlim_u = rlim;
+        if constexpr (unify) {
+            i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end);
+            cl = __builtin_amdgcn_readfirstlane(cl); clit = __builtin_amdgcn_readfirstlane(clit);
+            ilim_u = __builtin_amdgcn_readfirstlane(ilim); rlim_u = __builtin_amdgcn_readfirstlane(rlim);
+        }
 #ifdef LZANI_PATH_STATS
         int why = 0;
 #define LZ_SC_WHY(n) "s_mov_b32 %[why], " #n "\n\t"
@@ -2115,6 +2146,8 @@ struct DevWave {
 #undef LZ_NC_ROUND_X
 #undef LZ_NC_ROUND_F
 #undef LZ_NC_ASM
+#undef LZ_NC_ASM_X
+#undef LZ_NC_SPLITCHK
 #undef LZ_NC_WORD7
 #undef LZ_NC_WORD7N
 #undef LZ_NC_WORD9

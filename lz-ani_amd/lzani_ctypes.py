@@ -50,7 +50,8 @@ class LayoutInfo(C.Structure):
                 ("slots", C.c_uint32), ("batches_last_run", C.c_uint32), ("bytes_per_slot", C.c_uint64),
                 ("bytes_genomes", C.c_uint64), ("join_lists", C.c_int32), ("block_launches", C.c_int32),
                 ("bitmap_launches", C.c_int32), ("rtc_launches", C.c_int32),
-                ("lpt_launches", C.c_int32), ("matrix_from_index", C.c_int32)]
+                ("lpt_launches", C.c_int32), ("matrix_from_index", C.c_int32), ("split_launches", C.c_int32), ("reserved_", C.c_int32),
+                ("split_segments", C.c_uint64)]
 
 
 class RtcInfo(C.Structure):
@@ -61,7 +62,7 @@ class RtcInfo(C.Structure):
 def build_library(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     deps = [SRC] + [os.path.join(HERE, "csrc", h) for h in ("lzani_core.h", "lzani_layout.h", "lzani_kernels_index.h",
-                                                             "lzani_kernels_cand.h", "lzani_kernels_pairs.h", "lzani_multi.h", "lzani_sort.hip", "lzani_tables.h", "lzani_rtc.h")] + [os.path.join(ROOT, "include", "lzani.h")]
+                                                             "lzani_kernels_cand.h", "lzani_kernels_pairs.h", "lzani_kernels_split.h", "lzani_multi.h", "lzani_sort.hip", "lzani_tables.h", "lzani_rtc.h")] + [os.path.join(ROOT, "include", "lzani.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

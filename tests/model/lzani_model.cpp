@@ -96,6 +96,8 @@ struct HostWave {
     std::vector<RegionCoords>* regs = nullptr;
     void emit_region(const RegionCoords& c) const { if (regs) regs->push_back(c); }
     void stamp(int) const {}
+    void split_limit(int) const {}
+    int uniform(int v) const { return v; }
     bool ext_record(u32&) const { return false; }
     u64 mism_fwd(int q0, int r0, int n) const
     {
@@ -169,6 +171,68 @@ int model_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t* len, 
             PairMachine<HostWave> m(w, P, G[r].T, G[q].D);
             int res[3];
             m.run(res);
+            o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+        }
+    return 0;
+}
+
+// One pair by several segments (lzani_core.h: SplitStart / run_checkpoint / run_segment / split_stitch), cuts every `seglen`
+// query positions: out as model_all2all; stats[0] = pairs stitched, [1] = pairs the stitch voided (scanned whole instead),
+// [2] = segments in all, [3] = segments whose work the chain of hand-overs skipped.
+int model_split_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t* len, const int32_t* p8, int32_t seglen, int32_t* out, int64_t* stats)
+{
+    Params P{p8[0], p8[1], p8[2], p8[3], p8[4], p8[5], p8[6], p8[7]};
+    if (!params_supported(P) || seglen < 1) return -1;
+    uint32_t maxL = 0;
+    for (uint32_t i = 0; i < n; ++i) maxL = std::max(maxL, len[i]);
+    IndexGeom geo = index_geometry(ref_text_len((int)maxL, P.mrd), P.mal);
+    std::vector<Genome> G(n);
+    for (uint32_t i = 0; i < n; ++i) { pack_genome(G[i], codes[i], (int)len[i], P); build_index(G[i], P, geo); }
+    for (int k = 0; k < 4; ++k) stats[k] = 0;
+    for (uint32_t r = 0; r < n; ++r)
+        for (uint32_t q = 0; q < n; ++q) {
+            int32_t* o = out + ((size_t)r * n + q) * 3;
+            if (r == q) { o[0] = o[1] = o[2] = 0; continue; }
+            const int D = G[q].D, ncut = std::max(1, (D + seglen - 1) / seglen);
+            std::vector<SplitStart> cuts(ncut);
+            std::vector<SplitOut> segs(ncut);
+            for (int j = 1; j < ncut; ++j) {
+                HostWave w{P, G[r].rview(), G[q].qview(), G[r].iv};
+                PairMachine<HostWave> m(w, P, G[r].T, D);
+                m.run_checkpoint(j * seglen, &cuts[j]);
+            }
+            cuts[0] = SplitStart{0, 0, -1, 0, 0, 0};
+            for (int j = 0; j < ncut; ++j) {
+                HostWave w{P, G[r].rview(), G[q].qview(), G[r].iv};
+                PairMachine<HostWave> m(w, P, G[r].T, D);
+                if (j > 0 && cuts[j].i < 0) { segs[j] = SplitOut{}; segs[j].first = 2; continue; }
+                m.run_segment(j, j ? &cuts[j] : nullptr, cuts.data(), ncut, &segs[j]);
+            }
+            int res[3];
+            stats[2] += ncut;
+            // a void segment: its cut is disabled and the segment that handed over to it runs again (as the device does, round by round)
+            bool ok = false;
+            for (int round = 0; round < 8 && !ok; ++round) {
+                int at = -1, from = -1;
+                ok = split_stitch(cuts.data(), segs.data(), ncut, P.reg, res, &at, &from);
+                if (ok || at < 0 || from < 0) break;
+                cuts[at].i = -1;
+                HostWave w{P, G[r].rview(), G[q].qview(), G[r].iv};
+                PairMachine<HostWave> m(w, P, G[r].T, D);
+                m.run_segment(from, from ? &cuts[from] : nullptr, cuts.data(), ncut, &segs[from]);
+                stats[1] += 1;                       // (counted: segments run again)
+            }
+            if (ok) {
+                stats[0] += 1;
+                int used = 0;
+                for (int j = 0; j >= 0 && j < ncut; j = segs[j].stop) { ++used; if (segs[j].stop < 0) break; }
+                stats[3] += ncut - used;
+            } else {
+                stats[3] += 1000000;                 // (counted apart: pairs scanned whole after all)
+                HostWave w{P, G[r].rview(), G[q].qview(), G[r].iv};
+                PairMachine<HostWave> m(w, P, G[r].T, D);
+                m.run(res);
+            }
             o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
         }
     return 0;

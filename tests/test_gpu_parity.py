@@ -616,6 +616,41 @@ def test_matrix_from_index_and_longest_pair_first_forced(monkeypatch):
         assert np.array_equal(base, want) and np.array_equal(got, want), (len(seqs), prm)
 
 
+def test_pairs_split_over_several_waves_forced(monkeypatch):
+    """Few, long pairs by several waves each (lzani_kernels_split.h: checkpoints, segments, stitch, void segments run again)
+    at sizes the oracle covers whole, forced by the environment with cuts every 1,500-6,000 query positions: related and
+    unrelated pairs, default and long-k-mer parameters (the hand-written loops inside the segments), genomes with N (the
+    generic instantiation's bounds), a run-time parameter tuple on the generic kernel.  Equal to the unsplit run and to
+    the oracle; the layout info says the pairs were split."""
+    withn = [s.copy() for s in SG.make_set(20, 24, lmin=17000, lmax=21000, fam=5)[1]]
+    for k in range(0, 20, 3):
+        withn[k][400:400 + 9 + 2 * k] = 5
+    cases = [(SG.make_set(30, 21, lmin=17000, lmax=21000, fam=6)[1], None, 2000),
+             (SG.make_set(24, 23, lmin=60_000, lmax=90_000, fam=4, dmin=0.005, dmax=0.08)[1], dict(mal=15, msl=9, reg=60), 6000),
+             (withn, None, 1500),
+             (SG.make_set(16, 25, lmin=30_000, lmax=40_000, fam=4)[1], dict(reg=50, aw=12, am=5), 3000)]
+    monkeypatch.setenv("LZANI_PM_MIN_ROWS", "1")
+    for seqs, prm, seglen in cases:
+        want = O.oracle_all2all(seqs, prm, threads=16)
+        eng = L.Engine(prm)
+        eng.set_genomes(seqs)
+        base = eng.all2all()
+        assert eng.layout()["split_launches"] == 0
+        monkeypatch.setenv("LZANI_SPLIT", "1")
+        monkeypatch.setenv("LZANI_SPLIT_SEGLEN", str(seglen))
+        got = eng.all2all()
+        lay = eng.layout()
+        monkeypatch.delenv("LZANI_SPLIT")
+        monkeypatch.delenv("LZANI_SPLIT_SEGLEN")
+        eng.close()
+        n = len(seqs)
+        assert lay["split_launches"] == 1 and lay["split_segments"] >= 2 * n * (n - 1), lay
+        print(f"split: {n} genomes, cuts every {seglen}: {lay['split_segments']} segments run for {n * (n - 1)} pairs")
+        bad = np.argwhere((got != want).any(axis=2))
+        assert len(bad) == 0, (prm, seglen, bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
+        assert np.array_equal(base, want)
+
+
 def test_long_genomes_presence_matrix_natural_trigger():
     """BASELINE configs[3] at its own geometry with enough genomes that the candidate-bitmap form is chosen BY ITSELF (dense
     rows, >= 32 of them: no LZANI_PM_MIN_ROWS): 33 genomes of 4.6-5.2 Mbp in four families, --mal 15 --msl 9 --reg 60 --
@@ -639,7 +674,8 @@ def test_long_genomes_presence_matrix_natural_trigger():
     eng.close()
     assert lay["bitmap_launches"] >= 1 and lay["bitmap_launches"] == lay["batches_last_run"] and lay["join_lists"] == 1, lay
     # (round 4) at this geometry the matrix comes from the batch's indexes and the tickets go longest pair first, by themselves
-    assert lay["matrix_from_index"] >= 1 and lay["lpt_launches"] == lay["bitmap_launches"], lay
+    # ... or, with as few pairs as here (1,056 on 8,192 wave slots), every pair is scanned by several waves (lzani_kernels_split.h)
+    assert lay["matrix_from_index"] >= 1 and lay["lpt_launches"] + lay["split_launches"] == lay["bitmap_launches"], lay
     print(f"33 x 5 Mbp: pair kernel {tm['pairs_ms']:.0f} ms, candidate stage {tm['cand_ms']:.0f} ms, index {tm['index_ms']:.0f} ms, k-mer words {tm['kmers_ms']:.0f} ms")
     lens = np.array([len(s) for s in seqs])
     fam = np.array(fam)

@@ -179,3 +179,31 @@ def test_ext_record_narrow_form_equals_wide_form():
             rp[k] = max(0, min(T - 1, e)); qp[k + 32] = max(0, min(len(q) + prm["mrd"] - 1, e if e < len(q) else len(q) - (k % 40)))
         bad = lib.model_ext_records_agree(O._ptr(r), len(r), O._ptr(q), len(q), O.params_array(prm), n, O._ptr(qp), O._ptr(rp), O._ptr(al))
         assert bad == 0, (it, prm, bad)
+
+
+def test_split_pairs_model_against_oracle():
+    """One pair by several segments (lzani_core.h: SplitStart / run_checkpoint / run_segment / split_stitch, the formulation
+    behind lzani_kernels_split.h) through the host model: cuts every few hundred to few thousand query positions, every
+    hand-over an equality of states, void segments run again with their cut disabled -- results equal to the oracle's for
+    related and unrelated pairs, default and long-genome parameters, and every pair gets through the stitch."""
+    for seed, (lmin, lmax, fam, dmax) in enumerate([(5000, 9000, 4, 0.15), (8000, 12000, 6, 0.05), (3000, 4000, 1, 0.15)]):
+        _, seqs = SG.make_set(8, 60 + seed, lmin=lmin, lmax=lmax, fam=fam, dmax=dmax)
+        for prm in (None, dict(mal=15, msl=9, reg=60), dict(mqd=20, mrd=30, reg=20)):
+            want = O.oracle_all2all(seqs, prm, threads=8)
+            for seglen in (300, 1000, 2500):
+                got, st = U.model_split_all2all(seqs, prm, seglen)
+                assert np.array_equal(got, want), (seed, prm, seglen)
+                assert st[0] == len(seqs) * (len(seqs) - 1) and st[3] < 1000000, (seed, prm, seglen, st.tolist())     # every pair stitched, none scanned whole
+    E = U.edge_set()
+    for prm in (None, dict(mal=15, msl=9, reg=60), dict(mrd=0), dict(reg=1), dict(aw=64, am=20)):
+        got, _ = U.model_split_all2all(E, prm, 200)
+        assert np.array_equal(got, O.oracle_all2all(E, prm, threads=8)), prm
+
+
+def test_split_pairs_model_fuzz():
+    st = SG.Stream(4242)
+    for it in range(400):
+        prm, seqs = U.fuzz_case(st)
+        want = O.oracle_all2all(seqs, prm, threads=4)
+        got, _ = U.model_split_all2all(seqs, prm, 64 + 37 * (it % 9))
+        assert np.array_equal(got, want), (it, prm)

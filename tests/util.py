@@ -168,6 +168,20 @@ def model_all2all(seqs, params=None):
     return out
 
 
+def model_split_all2all(seqs, params=None, seglen=1000):
+    """Every pair by several segments (lzani_core.h: checkpoints, segments, stitch) through the host model: (results, stats)
+    with stats = [pairs stitched, pairs the stitch voided, segments in all, segments skipped by the hand-overs]."""
+    lib = model_lib()
+    seqs, ptrs, lens = O._seq_table(seqs)
+    n = len(seqs)
+    out = np.zeros((n, n, 3), dtype=np.int32)
+    stats = np.zeros(4, dtype=np.int64)
+    rc = lib.model_split_all2all(n, ptrs, O._ptr(lens), O.params_array(params), int(seglen), O._ptr(out), O._ptr(stats))
+    if rc != 0:
+        raise ValueError("model: unsupported parameters")
+    return out, stats
+
+
 def model_pair_regions(ref, qry, params=None):
     """(result triple, regions sorted like calc_regions) through the ALN instantiation of the model."""
     lib = model_lib()
