@@ -660,6 +660,9 @@ template <class W> struct wave_has_stretch_chain<W, std::void_t<decltype(W::HAS_
 // of segments; a first region that the segment drops, or that the true scan would drop, voids the split (the pair is then
 // scanned whole).  Exact by construction: every hand-over is an equality of states.  (parser.cpp:482-716 has no
 // counterpart: one thread scans one pair.)
+#ifdef LZ_SPLIT_DEBUG
+static long g_split_why[8];
+#endif
 struct SplitStart {                  // where a segment starts: the state behind the first event of a fresh scan from the cut
     int i, r_end, prev_rs, pre_lit, cl, clit;        // lit = 0, tracking, prev_re = i, nl = 0;  i = -1: no checkpoint (no event behind the cut, or the cut is disabled)
 };
@@ -678,6 +681,8 @@ struct SplitOut {
     int assumed;                     // at the close of the first region the segment went on as if the true scan 1 kept / 2 dropped it (0: not closed)
     int first_floor;                 // assumed = 2: the segment's floor then (the stitch wants the true floor at or below it)
     int synced, floor;               // at the stop: the segment's floor is the true one (it kept a region) / its value
+    int stop_i, stop_r;              // the state it stopped in (the checkpoint's i, r_end): with the fields above, all a RESUMED scan needs -- when the
+                                     // segment it handed over to turns out void, that cut is disabled and this segment goes on from here
 };
 // the stitch of one pair: seg[0 .. n) in cut order, starts[j] = the checkpoint of cut j (j >= 1); false = void (scan the pair whole)
 // void_at / void_from (optional): the segment whose work is void and the one that handed over to it -- run that one again with
@@ -686,6 +691,11 @@ LZ_HD bool split_stitch(const SplitStart* starts, const SplitOut* seg, int n, in
 {
     int from = -1;
     if (void_at) { *void_at = -1; *void_from = -1; }
+#ifdef LZ_SPLIT_DEBUG
+#define LZ_SPLIT_WHY(k) (++g_split_why[k])
+#else
+#define LZ_SPLIT_WHY(k) ((void)0)
+#endif
 #define LZ_SPLIT_VOID(at) do { if (void_at) { *void_at = (at); *void_from = from; } return false; } while (0)
     int tm = 0, tl = 0, tc = 0;
     int open_cl = 0, open_clit = 0, open_rs = -1;          // the TRUE open region at the current segment's start
@@ -693,15 +703,15 @@ LZ_HD bool split_stitch(const SplitStart* starts, const SplitOut* seg, int n, in
     int j = 0;
     for (int guard = 0; guard <= n; ++guard) {
         const SplitOut& o = seg[j];
-        if (o.first == 2) LZ_SPLIT_VOID(j > 0 ? j : -1);
+        if (o.first == 2) { LZ_SPLIT_WHY(0); LZ_SPLIT_VOID(j > 0 ? j : -1); }
         int t_cl = o.open_cl, t_clit = o.open_clit, t_rs = o.open_rs;      // the true open region at the segment's stop
         if (j > 0) {
             const SplitStart& st = starts[j];
             if (o.first == 1) {                            // the first region closed inside: its true counts, the keep test on the true span
                 const int cl = open_cl - st.cl + o.first_cl, clit = open_clit - st.clit + o.first_clit;
                 const bool dropped = open_rs >= 0 && o.first_re - open_rs < reg;       // by the true scan: its start is the true one
-                if (o.assumed == 1 && dropped) LZ_SPLIT_VOID(j);       // the segment went on as if it were kept
-                if (o.assumed == 2 && (!dropped || floor > o.first_floor)) LZ_SPLIT_VOID(j);   // ... dropped, looking back to its own floor
+                if (o.assumed == 1 && dropped) { LZ_SPLIT_WHY(1); LZ_SPLIT_VOID(j); }      // the segment went on as if it were kept
+                if (o.assumed == 2 && (!dropped || floor > o.first_floor)) { LZ_SPLIT_WHY(dropped ? 3 : 2); LZ_SPLIT_VOID(j); }   // ... dropped, looking back to its own floor
                 if (!dropped && cl && cl + clit >= reg) { tm += cl; tl += clit; ++tc; }
             } else {                                       // still open at the stop: the true region goes on
                 t_cl = open_cl - st.cl + o.open_cl; t_clit = open_clit - st.clit + o.open_clit; t_rs = open_rs;
@@ -884,6 +894,9 @@ struct PairMachine {
     // later checkpoint the scan passes through (cuts seg + 1 .. n_cuts - 1), or to the end of the query
     LZ_HD void run_segment(int seg, const SplitStart* start, const SplitStart* cuts, int n_cuts, SplitOut* so)
     { int dummy[3]; run_impl<2>(dummy, seg, start, cuts, n_cuts, 0, so, nullptr); }
+    // the same segment on from where it stopped (its record *so is its state), past the cut it stopped at
+    LZ_HD void resume_segment(int seg, const SplitStart* cuts, int n_cuts, SplitOut* so)
+    { int dummy[3]; run_impl<2>(dummy, seg, nullptr, cuts, n_cuts, -1, so, nullptr); }
     // the checkpoint of a cut at query position p0: a fresh scan from there through its first event
     LZ_HD void run_checkpoint(int p0, SplitStart* cp)
     { int dummy[3]; run_impl<1>(dummy, 0, nullptr, nullptr, 0, p0, nullptr, cp); }
@@ -902,9 +915,18 @@ struct PairMachine {
         [[maybe_unused]] int next_cut = 0, events = 0, lim_i = -1;
         if constexpr (SPLIT == 1) { i = p0; cp->i = -1; cp->r_end = cp->prev_rs = cp->pre_lit = cp->cl = cp->clit = 0; }
         if constexpr (SPLIT == 2) {
+          if (p0 < 0) {                             // resumed: the record is the state
+            i = w.uniform(so->stop_i); r_end = w.uniform(so->stop_r); trk = true;
+            prev_rs = w.uniform(so->open_rs); prev_re = i; pre_lit = prev_rs - w.uniform(so->floor);
+            g.cl = w.uniform(so->open_cl); g.clit = w.uniform(so->open_clit);
+            g.tm = w.uniform(so->tm); g.tl = w.uniform(so->tl); g.tc = w.uniform(so->tc);
+            first_open = w.uniform(so->first) == 0; tainted = w.uniform(so->synced) == 0;
+            next_cut = w.uniform(so->stop) + 1;
+            so->stop = -1;
+          } else {
             so->tm = so->tl = so->tc = 0; so->first = 3; so->first_cl = so->first_clit = so->first_re = 0;
             so->stop = -1; so->open_cl = so->open_clit = 0; so->open_rs = -1;
-            so->assumed = 0; so->first_floor = 0; so->synced = 1; so->floor = 0;
+            so->assumed = 0; so->first_floor = 0; so->synced = 1; so->floor = 0; so->stop_i = so->stop_r = 0;
             next_cut = seg + 1;
             if (start) {
                 // (w.uniform: a value out of memory, the same in every lane -- the device's policy says so to the compiler)
@@ -913,14 +935,18 @@ struct PairMachine {
                 g.cl = w.uniform(start->cl); g.clit = w.uniform(start->clit);
                 first_open = true; tainted = true; so->first = 0;
             }
+          }
         }
 
         while (i < iend) {
             if (++rounds > D + 8) { LZ_GUARD_TRIP(3); out[0] = -1; out[1] = i; out[2] = lit; return; }
             if constexpr (SPLIT == 1) {
-                if (events) {                    // the state behind the first event: the checkpoint (an event leaves lit = 0, tracking)
+                if (events && trk && lit == 0) {
+                    // behind an event of the fresh scan's FIRST region: a checkpoint (an event leaves lit = 0, tracking).  The later the
+                    // better, up to a point: once the region spans reg positions the segment that starts here knows how it will be
+                    // closed (kept) -- a shorter piece of a long true region is what voids most segments of related pairs
                     cp->i = i; cp->r_end = r_end; cp->prev_rs = prev_rs; cp->pre_lit = pre_lit; cp->cl = g.cl; cp->clit = g.clit;
-                    return;
+                    if (prev_re - prev_rs >= P.reg || events >= 8) return;
                 }
             }
             if constexpr (SPLIT == 2) {
@@ -932,7 +958,7 @@ struct PairMachine {
                         if (ci == i && trk && lit == 0 && w.uniform(cuts[k].r_end) == r_end) {         // behind an event, in the checkpoint's very state: hand over
                             so->tm = g.tm; so->tl = g.tl; so->tc = g.tc;
                             so->stop = k; so->open_cl = g.cl; so->open_clit = g.clit; so->open_rs = prev_rs;
-                            so->synced = !tainted; so->floor = prev_rs - pre_lit;
+                            so->synced = !tainted; so->floor = prev_rs - pre_lit; so->stop_i = i; so->stop_r = r_end;
                             return;
                         }
                         if (ci > i) lim_i = imin(lim_i, ci);
@@ -1001,7 +1027,11 @@ struct PairMachine {
                 if (lit > P.mqd) trk = false;
                 continue;
             }
-            if constexpr (SPLIT == 1) events = 1;
+            if constexpr (SPLIT == 1) {
+                // (a distant match behind the first event would close the first region: the checkpoint is the state before it)
+                if (events && !(trk && lit <= P.mqd && iabs(bpos - (r_end + lit)) <= P.mrd)) return;
+                events += 1;
+            }
 #if defined(LZANI_EXP) && LZANI_EXP >= 1                     // diagnostic build: events found but not processed
             i += blen; r_end = bpos + blen; lit = 0; trk = true; prev_re = i;
             continue;

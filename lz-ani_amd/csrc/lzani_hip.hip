@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -572,7 +573,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
         // (from 32 rows on where the probe form with tag words is the alternative; from 8 rows where it is the rounds of the
         // first kernel: genomes whose tags do not fit a tag byte -- 260 kbp to 2 Mbp at mal 15, viral sizes at mal 13+.
         // Below, the matrix -- 16 GB to clear at 30 key bits -- costs more than it saves.)
-        const u32 min_rows = mn ? (u32)std::max(1, atoi(mn)) : c->tw_stride ? 32u : 8u;
+        // Long genomes (the join is the alternative: 210 ms for the 56 pairs of 8 x 5 Mbp against 149 by bitmaps, 92 with the
+        // pairs cut into segments): from two rows on.
+        const u32 min_rows = mn ? (u32)std::max(1, atoi(mn)) : c->join_mode ? 2u : c->tw_stride ? 32u : 8u;
         // Query lists qualify when they are dense where they are: a query that occurs in a group of rows should meet a
         // good part of it (one matrix row read serves all its pairs of the group) -- the row x column blocks of a tiled
         // all2all do, the few relatives a kmer-db filter leaves per row do not.  No query twice in a row (one bitmap each).
@@ -795,7 +798,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             int Lmax = 0;
             for (u32 g = 0; g < c->n; ++g) Lmax = std::max(Lmax, c->L[g]);
             const int Dmax = Lmax + c->P.mrd;
-            const bool on = se ? *se == '1' : (cb_words >= 8192 && bp * 2 <= slots);
+            // (measured, round 4: with 56 pairs of 5 Mbp a launch takes 92 ms instead of 148, with 240 pairs 126 instead of 147,
+            // with 992 pairs the rounds of segments run again cost more than the cuts save: from 16 wave slots per pair on)
+            const bool on = se ? *se == '1' : (cb_words >= 8192 && bp * 16 <= slots);
             if (on && bp * 2 <= 0xFFFFFFFFull / 64) {
                 u32 S = (u32)std::min<u64>(16, std::max<u64>(2, slots / bp));
                 int seglen = (Dmax + (int)S - 1) / (int)S;
@@ -805,11 +810,12 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             }
         }
         bool lpt = false;
-        if (pm && e1 > e0 && split_S < 2) {
+        if (pm && e1 > e0) {
             const char* le = getenv("LZANI_LPT");
             const u64 bp = e1 - e0;
             lpt = !rs && bp >= 2 && bp <= (u64)max_blocks * 4 * 32 && (le ? *le == '1' : cb_words >= 8192);     // (queries from ~256 kbp on)
             if (le && *le == '0') lpt = false;
+            if (split_S >= 2) lpt = true;                        // (the split wants the candidate counts: which pairs to cut, which first)
             if (lpt && c->lpt_pairs < bp) {
                 hipFree(c->d_lpt_cnt); hipFree(c->d_lpt_keys);
                 c->d_lpt_cnt = nullptr; c->d_lpt_keys = nullptr; c->lpt_pairs = 0;
@@ -903,7 +909,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 }
                 c->tm.cand_launches += 2;
             }
-            if (lpt) {                                       // the ticket order of the batch's queues
+            if (lpt && c->d_lpt_cnt == nullptr) split_S = 0;     // (no counts after all: no split)
+            if (lpt && split_S < 2) {                        // the ticket order of the batch's queues
                 const u64 bp = e1 - e0;
                 QueueBounds qbv;
                 for (int x = 0; x <= NQUEUES; ++x) qbv.v[x] = qb[(size_t)b * (NQUEUES + 1) + x];
@@ -941,8 +948,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             pa.cbits = d_cbits.p; pa.cbits_stride = cbits_stride; pa.cb_e0 = 0;
             if (pm) { pa.cbits = reinterpret_cast<unsigned long long*>(c->d_pm_cbits); pa.cbits_stride = cb_words / 2; pa.cb_e0 = e0; }
             pa.reg_out = rs ? rs->d_regions : nullptr; pa.reg_count = rs ? rs->d_count : nullptr; pa.reg_cap = rs ? rs->capacity : 0;
-            pa.torder = lpt ? c->d_lpt_keys + (e1 - e0) : nullptr;
-            c->lpt_launches += lpt ? 1 : 0;
+            pa.torder = (lpt && split_S < 2) ? c->d_lpt_keys + (e1 - e0) : nullptr;
+            c->lpt_launches += (lpt && split_S < 2) ? 1 : 0;
             HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, NQUEUES * sizeof(unsigned long long), c->stream));
             const u64 waves = e1 - e0;
             const dim3 gd((u32)std::min<u64>((waves + 3) / 4, max_blocks)), bd(256);
@@ -988,7 +995,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 DevBuf<SplitStart> d_cuts;
                 DevBuf<SplitOut> d_souts;
                 DevBuf<u32> d_work, d_next, d_cnt;
-                DevBuf<unsigned char> d_done;
+                DevBuf<unsigned char> d_done, d_heavy;
                 HIPCHK(c, d_cuts.alloc((size_t)npb * S));
                 HIPCHK(c, d_souts.alloc((size_t)npb * S));
                 HIPCHK(c, d_work.alloc((size_t)npb * S));
@@ -1011,15 +1018,38 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                     else { if (dsel == 1) LZ_SPLIT(false, 1); else if (dsel == 2) LZ_SPLIT(false, 2); else LZ_SPLIT(false, 0); }
 #undef LZ_SPLIT
                 };
-                launch(0, npb * (S - 1));                                  // the checkpoints
+                // which pairs to cut: the ones with many anchor candidates (related: a candidate at every other position; a chance
+                // pair has one in a hundred and is scanned whole, by its segment 0 with the null chain at work) -- heaviest first
+                u32 items = 0;
                 {
-                    std::vector<u32> all((size_t)npb * S);
-                    for (size_t k = 0; k < all.size(); ++k) all[k] = (u32)k;
+                    std::vector<u32> cnt(npb);
+                    HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_lpt_cnt, (size_t)npb * 4, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    const char* he = getenv("LZANI_SPLIT_ALL");
+                    const char* te = getenv("LZANI_SPLIT_THR");
+                    // (every pair by default: at a wave or two per SIMD a chance pair of 5 Mbp takes nearly as long as a related one;
+                    // LZANI_SPLIT_ALL=0 cuts the pairs with a candidate at one position in 32 and more only)
+                    const u32 thr = (he && *he == '0') ? (u32)(cb_words * 32 / 32) : te ? (u32)strtoul(te, nullptr, 10) : 0u;
+                    std::vector<u32> order(npb);
+                    for (u32 k = 0; k < npb; ++k) order[k] = k;
+                    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return cnt[x] > cnt[y]; });
+                    std::vector<unsigned char> heavy(npb, 0);
+                    std::vector<u32> all;
+                    all.reserve((size_t)npb * 2);
+                    u32 n_heavy = 0;
+                    for (u32 k : order) if (cnt[k] >= thr) { heavy[k] = 1; ++n_heavy; for (u32 sg = 0; sg < S; ++sg) all.push_back(k * S + sg); }
+                    for (u32 k : order) if (cnt[k] < thr) all.push_back(k * S);
+                    items = (u32)all.size();
+                    HIPCHK(c, d_heavy.alloc(npb));
+                    HIPCHK(c, hipMemcpyAsync(d_heavy.p, heavy.data(), npb, hipMemcpyHostToDevice, c->stream));
                     HIPCHK(c, hipMemcpyAsync(d_work.p, all.data(), all.size() * 4, hipMemcpyHostToDevice, c->stream));
-                    HIPCHK(c, hipStreamSynchronize(c->stream));            // (`all` leaves scope)
+                    HIPCHK(c, hipStreamSynchronize(c->stream));            // (the vectors leave scope)
+                    TRACE("split: %u pairs, %u of them cut into %u segments (candidates >= %u)", npb, n_heavy, S, thr);
                 }
-                u32 items = npb * S;
+                sa.heavy = d_heavy.p;
+                launch(0, npb * (S - 1));                                  // the checkpoints
                 u32* cur = d_work.p; u32* nxt = d_next.p;
+                auto t_round = std::chrono::steady_clock::now();
                 for (int round = 0; round < 12 && items; ++round) {
                     HIPCHK(c, hipMemsetAsync(d_cnt.p, 0, 8, c->stream));     // tickets, next round's items (the finished pairs' count stays)
                     sa.work = cur; sa.work_next = nxt;
@@ -1030,6 +1060,12 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                     HIPCHK(c, hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
                     HIPCHK(c, hipStreamSynchronize(c->stream));
                     c->split_items += items;
+                    {
+                        const auto t_now = std::chrono::steady_clock::now();
+                        TRACE("split: round %d ran %u segments in %.1f ms, %u pairs finished, %u segments to run again", round, items,
+                              std::chrono::duration<double, std::milli>(t_now - t_round).count(), cnt[2], cnt[1]);
+                        t_round = t_now;
+                    }
                     items = cnt[1];
                     std::swap(cur, nxt);
                     if (items == 0 && cnt[2] != npb) return fail(c, LZANI_ERR_DEVICE, "split pairs: the stitch left pairs behind");

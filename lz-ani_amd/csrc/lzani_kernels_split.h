@@ -10,7 +10,8 @@
 // region counts along the chain of hand-overs.  Every hand-over is an equality of states, so the result is the whole
 // scan's, bit for bit; a segment whose work turns out void (its look-back bound cut a backward extension short, or the
 // region it started in ended the other way than it assumed) is dropped from the chain -- its cut disabled -- and the
-// segment before it runs again, round by round, until the stitch gets through (at worst segment 0 scans the whole pair).
+// segment before it goes on from where it stopped, round by round, until the stitch gets through (at worst segment 0 scans
+// the whole pair).
 //
 //   k_split<.., 0>  checkpoints: one wave per (pair, cut >= 1)
 //   k_split<.., 1>  segments:    one wave per work item (pair, segment)
@@ -34,6 +35,7 @@ struct SplitArgs {
     unsigned char* done;         // per pair: stitched and stored
     int reg;
     int last_round;              // the stitch: a pair that still does not get through has all its cuts disabled and segment 0 listed
+    const unsigned char* heavy;  // per pair: cut it (a related pair: many anchor candidates); the others are scanned whole, by segment 0
 };
 
 // the pair of batch-relative index p: its row (slot), reference, query and absolute result offset
@@ -50,7 +52,7 @@ __device__ __forceinline__ void split_pair_of(const SplitArgs& a, u32 p, u32& sl
 
 // MODE 0: the checkpoint of cut `seg` of pair p;  MODE 1: segment `seg` of pair p
 template <bool NFREE, int DEFP, int MODE>
-__device__ __forceinline__ void split_body(const SplitArgs& a, u32 p, u32 seg, int lane, u32* lds)
+__device__ __forceinline__ void split_body(const SplitArgs& a, u32 p, u32 seg, bool resume, int lane, u32* lds)
 {
     const Params Pk = DEFP ? folded_params(DEFP) : a.pa.P;
     u32 slot, r, q;
@@ -78,12 +80,16 @@ __device__ __forceinline__ void split_body(const SplitArgs& a, u32 p, u32 seg, i
         const int p0 = (int)seg * a.seglen;
         SplitStart cp;
         cp.i = -1; cp.r_end = cp.prev_rs = cp.pre_lit = cp.cl = cp.clit = 0;
-        if (p0 < w.iend) { w.scan_pos = p0; m.run_checkpoint(p0, &cp); }
+        if (p0 < w.iend && a.heavy[p]) { w.scan_pos = p0; m.run_checkpoint(p0, &cp); }
         cuts[seg] = cp;                       // (wave-uniform: every lane stores the same values)
     } else {
         // (the segment's record is written where it belongs as the scan goes: a handful of stores at rare events, no registers held)
         SplitOut* const so = a.outs + (u64)p * a.S + seg;
         const SplitStart st = cuts[seg];
+        if (resume) {                                    // on from where it stopped, past the (now disabled) cut it stopped at
+            w.scan_pos = Wave::uniform(so->stop_i);
+            m.resume_segment((int)seg, cuts, (int)a.S, so);
+        } else
         if (seg > 0 && Wave::uniform(st.i) < 0) {        // (its cut has no checkpoint: nothing hands over to it)
             so->tm = so->tl = so->tc = 0; so->first = 2; so->first_cl = so->first_clit = so->first_re = 0; so->stop = -1;
             so->open_cl = so->open_clit = 0; so->open_rs = -1; so->assumed = 0; so->first_floor = 0; so->synced = 0; so->floor = 0;
@@ -107,9 +113,10 @@ __global__ void __launch_bounds__(256, LZANI_WAVES_PER_SIMD) k_split(SplitArgs a
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= a.n_work) break;
         u32 p, seg;
+        bool resume = false;
         if (MODE == 0) { p = t / (a.S - 1); seg = 1 + t % (a.S - 1); }      // (n_work = n_pairs * (S - 1))
-        else { const u32 it = a.work[t]; p = it / a.S; seg = it % a.S; }
-        split_body<NFREE, DEFP, MODE>(a, p, seg, lane, lds);
+        else { const u32 it = a.work[t]; resume = (it >> 31) != 0; p = (it & 0x7FFFFFFFu) / a.S; seg = (it & 0x7FFFFFFFu) % a.S; }
+        split_body<NFREE, DEFP, MODE>(a, p, seg, resume, lane, lds);
     }
 }
 
@@ -128,11 +135,12 @@ __global__ void __launch_bounds__(256) k_split_stitch(SplitArgs a)
             atomicAdd(&a.counters[2], 1u);
             continue;
         }
+        u32 item;
         if (at < 0 || from < 0 || a.last_round) {          // nothing to retry (or out of rounds): segment 0 scans the pair whole
             for (u32 k = 1; k < a.S; ++k) cuts[k].i = -1;
-            from = 0;
-        } else cuts[at].i = -1;
-        a.work_next[atomicAdd(&a.counters[1], 1u)] = p * a.S + (u32)from;
+            item = p * a.S;
+        } else { cuts[at].i = -1; item = (p * a.S + (u32)from) | 0x80000000u; }     // (bit 31: resume, see split_body)
+        a.work_next[atomicAdd(&a.counters[1], 1u)] = item;
     }
 }
 

@@ -219,7 +219,7 @@ int model_split_all2all(uint32_t n, const uint8_t* const* codes, const uint32_t*
                 cuts[at].i = -1;
                 HostWave w{P, G[r].rview(), G[q].qview(), G[r].iv};
                 PairMachine<HostWave> m(w, P, G[r].T, D);
-                m.run_segment(from, from ? &cuts[from] : nullptr, cuts.data(), ncut, &segs[from]);
+                m.resume_segment(from, cuts.data(), ncut, &segs[from]);
                 stats[1] += 1;                       // (counted: segments run again)
             }
             if (ok) {

@@ -551,14 +551,16 @@ def test_bacterial_geometry_5mbp(monkeypatch):
     lay = eng.layout()
     assert (lay["key_bits"], lay["dir_bits"], lay["pos_bits"], lay["tag_mask"]) == (30, 24, 24, 0x3F)
     assert lay["kmer_words"] == 1 and lay["bucket_table"] == 1 and lay["tag_words"] == 1 and lay["join_lists"] == 1
+    monkeypatch.setenv("LZANI_PM_MIN_ROWS", "32")
     got = eng.all2all()
-    assert eng.layout()["bytes_per_slot"] > 400 << 20 and eng.layout()["bitmap_launches"] == 0      # (5 rows: candidates by the join)
-    # the same matrix with the candidates from the presence matrix, as dense runs of 32 rows and more take them: 2^30 rows
-    # of 16 bytes for a group of up to 128 references, the pair's bitmap 690 KB
-    monkeypatch.setenv("LZANI_PM_MIN_ROWS", "1")
-    got_pm = eng.all2all()
-    assert eng.layout()["bitmap_launches"] == 1
+    assert eng.layout()["bytes_per_slot"] > 400 << 20 and eng.layout()["bitmap_launches"] == 0      # (candidates by the join: the form of filtered rows)
     monkeypatch.delenv("LZANI_PM_MIN_ROWS")
+    # the same matrix the way dense rows of long genomes run by themselves (from two rows on since round 4): the candidates
+    # from the presence matrix -- 2^30 rows of 16 bytes for a group of up to 128 references, made from the batch's indexes,
+    # the pair's bitmap 690 KB -- and, the pairs being this few, every pair by 16 waves (lzani_kernels_split.h)
+    got_pm = eng.all2all()
+    lay = eng.layout()
+    assert lay["bitmap_launches"] == 1 and lay["matrix_from_index"] == 1 and lay["split_launches"] == 1 and lay["split_segments"] >= 16 * 20, lay
     eng.close()
     want = O.oracle_all2all(seqs, prm, threads=16)
     assert np.array_equal(got_pm, want)
@@ -638,13 +640,15 @@ def test_pairs_split_over_several_waves_forced(monkeypatch):
         assert eng.layout()["split_launches"] == 0
         monkeypatch.setenv("LZANI_SPLIT", "1")
         monkeypatch.setenv("LZANI_SPLIT_SEGLEN", str(seglen))
+        cut_all = seglen != 3000                      # (by default only the pairs with many anchor candidates -- the related ones -- are cut)
+        monkeypatch.setenv("LZANI_SPLIT_ALL", "1" if cut_all else "0")
         got = eng.all2all()
         lay = eng.layout()
-        monkeypatch.delenv("LZANI_SPLIT")
-        monkeypatch.delenv("LZANI_SPLIT_SEGLEN")
+        for k in ("LZANI_SPLIT", "LZANI_SPLIT_SEGLEN", "LZANI_SPLIT_ALL"):
+            monkeypatch.delenv(k)
         eng.close()
         n = len(seqs)
-        assert lay["split_launches"] == 1 and lay["split_segments"] >= 2 * n * (n - 1), lay
+        assert lay["split_launches"] == 1 and lay["split_segments"] >= (2 if cut_all else 1) * n * (n - 1), lay
         print(f"split: {n} genomes, cuts every {seglen}: {lay['split_segments']} segments run for {n * (n - 1)} pairs")
         bad = np.argwhere((got != want).any(axis=2))
         assert len(bad) == 0, (prm, seglen, bad[:4].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
@@ -710,6 +714,7 @@ def test_join_form_of_candidate_detection(monkeypatch):
     reference vectors, a seeded fuzz (N runs, inversions, random parameters), a multi-batch run and the filtered row
     form all go through it; results must not change."""
     monkeypatch.setenv("LZANI_JOIN_MIN_BYTES", "1")
+    monkeypatch.setenv("LZANI_PM", "0")          # (dense rows of long genomes take candidate bitmaps by themselves: here the join is the subject)
     with open(os.path.join(U.GOLD, "ref_vectors.json")) as f:
         vec = json.load(f)
     done = 0
