@@ -678,8 +678,9 @@ struct SplitOut {
     // of the last region the scan KEPT (a dropped region leaves it where it was: prev_rs - pre_lit).  A segment knows the true
     // floor from its first keep on; before, its own (the cut) is an upper bound of the true one, so its look-back is a lower
     // bound -- good as long as every backward scan breaks inside it (else first = 2).
-    int assumed;                     // at the close of the first region the segment went on as if the true scan 1 kept / 2 dropped it (0: not closed)
-    int first_floor;                 // assumed = 2: the segment's floor then (the stitch wants the true floor at or below it)
+    int assumed;                     // at the close of the first region the segment went on as if the true scan 1 kept / 2 dropped it / 3 kept it, on a guess (0: not closed)
+    int first_floor;                 // assumed = 2: the highest floor the segment's look-backs since hold for (the stitch wants the true floor at or below it);
+                                     // assumed = 3: the backward scan at the close was cut short
     int synced, floor;               // at the stop: the segment's floor is the true one (it kept a region) / its value
     int stop_i, stop_r;              // the state it stopped in (the checkpoint's i, r_end): with the fields above, all a RESUMED scan needs -- when the
                                      // segment it handed over to turns out void, that cut is disabled and this segment goes on from here
@@ -687,14 +688,18 @@ struct SplitOut {
 // the stitch of one pair: seg[0 .. n) in cut order, starts[j] = the checkpoint of cut j (j >= 1); false = void (scan the pair whole)
 // void_at / void_from (optional): the segment whose work is void and the one that handed over to it -- run that one again with
 // the void one's cut disabled and the stitch may get through (void_at = -1: nothing to retry)
-LZ_HD bool split_stitch(const SplitStart* starts, const SplitOut* seg, int n, int reg, int out[3], int* void_at = nullptr, int* void_from = nullptr)
+// why (optional): 0 a look-back cut short, 1 kept by the segment / dropped by the true scan, 2 the other way round, 3 the true
+// floor above what the segment's look-backs hold for, 4 kept on a guess and cut short, 5 a broken chain
+LZ_HD bool split_stitch(const SplitStart* starts, const SplitOut* seg, int n, int reg, int out[3], int* void_at = nullptr, int* void_from = nullptr,
+                        int* why = nullptr)
 {
     int from = -1;
     if (void_at) { *void_at = -1; *void_from = -1; }
+    if (why) *why = 5;
 #ifdef LZ_SPLIT_DEBUG
-#define LZ_SPLIT_WHY(k) (++g_split_why[k])
+#define LZ_SPLIT_WHY(k) do { ++g_split_why[k]; if (why) *why = (k); } while (0)
 #else
-#define LZ_SPLIT_WHY(k) ((void)0)
+#define LZ_SPLIT_WHY(k) do { if (why) *why = (k); } while (0)
 #endif
 #define LZ_SPLIT_VOID(at) do { if (void_at) { *void_at = (at); *void_from = from; } return false; } while (0)
     int tm = 0, tl = 0, tc = 0;
@@ -712,6 +717,7 @@ LZ_HD bool split_stitch(const SplitStart* starts, const SplitOut* seg, int n, in
                 const bool dropped = open_rs >= 0 && o.first_re - open_rs < reg;       // by the true scan: its start is the true one
                 if (o.assumed == 1 && dropped) { LZ_SPLIT_WHY(1); LZ_SPLIT_VOID(j); }      // the segment went on as if it were kept
                 if (o.assumed == 2 && (!dropped || floor > o.first_floor)) { LZ_SPLIT_WHY(dropped ? 3 : 2); LZ_SPLIT_VOID(j); }   // ... dropped, looking back to its own floor
+                if (o.assumed == 3 && dropped && o.first_floor) { LZ_SPLIT_WHY(4); LZ_SPLIT_VOID(j); }     // ... kept on a guess, and its look-back over the literals alone was cut short
                 if (!dropped && cl && cl + clit >= reg) { tm += cl; tl += clit; ++tc; }
             } else {                                       // still open at the stop: the true region goes on
                 t_cl = open_cl - st.cl + o.open_cl; t_clit = open_clit - st.clit + o.open_clit; t_rs = open_rs;
@@ -830,10 +836,11 @@ struct PairMachine {
     // try_extend_backward (parser.cpp:412-441)
     // bounded: set when the scan ended at the look-back bound max_len (no break before it, and the texts go on behind it) -- with a
     // larger bound the result might be another one (the split's segments look back over a lower bound of what the true scan may)
-    LZ_HD int extend_backward(int q0, int r0, int max_len, bool have0 = false, u64 B0 = 0, bool* bounded = nullptr)
+    // looked: the symbols the scan needed (up to its break; everything it was allowed where it did not break)
+    LZ_HD int extend_backward(int q0, int r0, int max_len, bool have0 = false, u64 B0 = 0, bool* bounded = nullptr, int* looked = nullptr)
     {
         int maxlen = imin(max_len, imin(q0, r0));
-        int last = 0;
+        int last = 0, seen = imax(maxlen, 0);
         u64 prevB = 0;
         bool broke = false;
         for (int base = 0; base < maxlen; base += 64) {
@@ -843,10 +850,11 @@ struct PairMachine {
             u64 qm = m.qual;
             if (m.brk) qm &= lowmask(ctz64(m.brk) + 1);
             if (qm) last = base + (63 - clz64(qm)) + 1;
-            if (m.brk) { broke = true; break; }
+            if (m.brk) { broke = true; seen = base + ctz64(m.brk) + 1; break; }
             prevB = B;
         }
         if (bounded) *bounded = !broke && max_len < imin(q0, r0);
+        if (looked) *looked = seen;
         return last;
     }
 
@@ -913,6 +921,8 @@ struct PairMachine {
         [[maybe_unused]] bool first_open = false;         // SPLIT 2: the region the segment started in is still open
         [[maybe_unused]] bool tainted = false;            //          how far back a distant match may look is known as a lower bound only
         [[maybe_unused]] int next_cut = 0, events = 0, lim_i = -1;
+        [[maybe_unused]] bool floor_own = false;          //          ... it stands on its own floor (first region dropped by its own view): the true one may be HIGHER
+        [[maybe_unused]] int need_floor = NO_CHECKPOINT;  //          ... and every look-back since holds for floors up to this one
         if constexpr (SPLIT == 1) { i = p0; cp->i = -1; cp->r_end = cp->prev_rs = cp->pre_lit = cp->cl = cp->clit = 0; }
         if constexpr (SPLIT == 2) {
           if (p0 < 0) {                             // resumed: the record is the state
@@ -921,6 +931,8 @@ struct PairMachine {
             g.cl = w.uniform(so->open_cl); g.clit = w.uniform(so->open_clit);
             g.tm = w.uniform(so->tm); g.tl = w.uniform(so->tl); g.tc = w.uniform(so->tc);
             first_open = w.uniform(so->first) == 0; tainted = w.uniform(so->synced) == 0;
+            floor_own = tainted && w.uniform(so->assumed) == 2;
+            if (floor_own) need_floor = w.uniform(so->first_floor);
             next_cut = w.uniform(so->stop) + 1;
             so->stop = -1;
           } else {
@@ -970,7 +982,9 @@ struct PairMachine {
             w.stamp(1);
             int in_hand = 0;
             if constexpr (wave_has_null_chain<W>::value && !ALN && SPLIT != 1) {
-                if (!(SPLIT == 2 && (first_open || tainted)))     // (the chain closes regions and looks back by itself: not while the first region is apart)
+                if constexpr (SPLIT == 2) w.split_taint_set(tainted);      // (the chain then keeps to what holds for every look-back)
+                if (!(SPLIT == 2 && (first_open || floor_own)))   // (the chain closes regions inside: not while the first one is apart; and its
+                                                                  // records want a look-back that is a LOWER bound of the true one)
                 // Straight after an event (tracking, nothing skipped yet) the policy may run the whole cycle
                 // "tracking round without a seed candidate -> next plain candidate -> distant null event over a dropped
                 // short region" for as many events as it lasts: exactly the updates of the null event below, nothing
@@ -1056,17 +1070,24 @@ struct PairMachine {
                 // and whether the true scan keeps or drops it is the stitch's to say: the segment goes on by its own view of the
                 // region's span and says which way it went -- see SplitOut)
                 [[maybe_unused]] bool sure = true;         // SPLIT 2: `avail` is the true scan's, not a lower bound of it
+                [[maybe_unused]] bool first_kept_guess = false;
                 const bool drop = prev_rs >= 0 && prev_re - prev_rs < P.reg;
                 if constexpr (SPLIT == 2) {
                     if (first_open) {
                         first_open = false;
                         so->first = 1; so->first_cl = g.cl; so->first_clit = g.clit; so->first_re = prev_re;
                         g.discard();
-                        if (drop) { so->assumed = 2; so->first_floor = prev_rs - pre_lit; sure = false; }
-                        else { so->assumed = 1; tainted = false; }
-                    } else if (tainted) { if (drop) sure = false; else tainted = false; }
+                        // (short in the segment's own view: the true region began earlier and may well be long enough -- a piece of a
+                        // real alignment rather than a chance anchor.  Going on as if KEPT is right whenever the true scan keeps, and
+                        // also when it drops but the backward scan below breaks inside the literals; going on as if DROPPED is right
+                        // only when the true scan drops.  So: kept, unless the region looks like a chance anchor's and the literals
+                        // are too few for a backward scan to break in them)
+                        if (!drop) { so->assumed = 1; tainted = false; }
+                        else if (lit >= 2 * P.aw || so->first_cl >= P.reg / 2) { so->assumed = 3; first_kept_guess = true; sure = false; }
+                        else { so->assumed = 2; so->first_floor = prev_rs - pre_lit; sure = false; floor_own = true; }
+                    } else if (tainted) { if (drop) sure = false; else { tainted = false; floor_own = false; } }
                 }
-                if (__builtin_expect(drop, 1)) {          // drop the short region
+                if (__builtin_expect(drop && !first_kept_guess, 1)) {          // drop the short region
                     avail = pre_lit + (i - prev_rs);
                     g.discard();
                     if (ALN) c.clear();
@@ -1110,11 +1131,21 @@ struct PairMachine {
                     w.mism2(fq, fr, 1, nf, i - 1, bpos - 1, -1, nb, Bf, Bb);
                     haveF = true;
                     if constexpr (SPLIT == 2) {
-                        if (nb > 0) b = extend_backward(i, bpos, avail, true, Bb, &bounded);
+                        if (nb > 0) {
+                            int looked = 0;
+                            b = extend_backward(i, bpos, avail, true, Bb, &bounded, &looked);
+                            // (a look-back that may be LONGER than the true scan's -- the segment dropped its first region by its own
+                            // view and stands on its own floor: the result holds for every floor at or below the scan's break)
+                            if (floor_own) need_floor = imin(need_floor, i - looked);
+                        }
                     } else
                     b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;
                 }
-                if constexpr (SPLIT == 2) { if (!sure && bounded) { so->first = 2; return; } }      // the lower bound cut the scan short: void
+                if constexpr (SPLIT == 2) {
+                    if (first_kept_guess) so->first_floor = bounded;          // (the stitch: void if the true scan dropped the region after all)
+                    else if (!sure && bounded) { so->first = 2; return; }     // the lower bound cut the scan short: void
+                    if (floor_own) so->first_floor = need_floor;              // (the stitch: the true floor at or below it)
+                }
                 g.finalize();                                           // a match_distant factor follows
                 region_close();
                 if (__builtin_expect(b > 0, 0)) {

@@ -1000,9 +1000,9 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 HIPCHK(c, d_souts.alloc((size_t)npb * S));
                 HIPCHK(c, d_work.alloc((size_t)npb * S));
                 HIPCHK(c, d_next.alloc((size_t)npb * S));
-                HIPCHK(c, d_cnt.alloc(4));
+                HIPCHK(c, d_cnt.alloc(12));
                 HIPCHK(c, d_done.alloc(npb));
-                HIPCHK(c, hipMemsetAsync(d_cnt.p, 0, 16, c->stream));
+                HIPCHK(c, hipMemsetAsync(d_cnt.p, 0, 48, c->stream));
                 HIPCHK(c, hipMemsetAsync(d_done.p, 0, npb, c->stream));
                 HIPCHK(c, hipMemsetAsync(d_cuts.p, 0xFF, (size_t)npb * S * sizeof(SplitStart), c->stream));      // (cut 0 of every pair: no checkpoint)
                 SplitArgs sa;
@@ -1056,14 +1056,14 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                     launch(1, items);
                     sa.last_round = round >= 6;
                     hipLaunchKernelGGL(k_split_stitch, dim3((npb + 255) / 256), dim3(256), 0, c->stream, sa);
-                    u32 cnt[4] = {0, 0, 0, 0};
-                    HIPCHK(c, hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, c->stream));
+                    u32 cnt[12] = {0};
+                    HIPCHK(c, hipMemcpyAsync(cnt, d_cnt.p, 48, hipMemcpyDeviceToHost, c->stream));
                     HIPCHK(c, hipStreamSynchronize(c->stream));
                     c->split_items += items;
                     {
                         const auto t_now = std::chrono::steady_clock::now();
-                        TRACE("split: round %d ran %u segments in %.1f ms, %u pairs finished, %u segments to run again", round, items,
-                              std::chrono::duration<double, std::milli>(t_now - t_round).count(), cnt[2], cnt[1]);
+                        TRACE("split: round %d ran %u segments in %.1f ms, %u pairs finished, %u segments to run again (void so far, by cause: look-back cut short %u, kept/dropped %u, dropped/kept %u, floor %u, guess %u, chain %u)",
+                              round, items, std::chrono::duration<double, std::milli>(t_now - t_round).count(), cnt[2], cnt[1], cnt[4], cnt[5], cnt[6], cnt[7], cnt[8], cnt[9]);
                         t_round = t_now;
                     }
                     items = cnt[1];

@@ -96,6 +96,8 @@ struct DevWave {
     int last_src = -1;   // queue entry the event just returned came from, if its null-extension record applies
     int stop_i = 0x7FFFFFFF;     // SPLITW: the query position of the nearest checkpoint ahead
     __device__ __forceinline__ void split_limit(int at) { stop_i = at; }
+    bool split_taint = false;    // SPLITW: the machine's look-back is a lower bound of the true scan's (lzani_core.h: SplitOut)
+    __device__ __forceinline__ void split_taint_set(bool t) { split_taint = t; }
     static __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
     enum { SPLIT_MARGIN = 256 };  // a chain call's last commit starts below the limit and moves less than this (gap <= mqd, match < 72 + a first extension chunk)
     u32 a_ext = EXT_REC_NONE;    // lane k: null-extension record of candidate k (lzani_core.h: null_ext_record)
@@ -887,6 +889,7 @@ struct DevWave {
         constexpr bool unify = SPLITW;                    // (a segment's state comes out of memory)
 #endif
         int qc_u = q_cnt, ilim_u = ilim, rlim_u = rlim;
+        [[maybe_unused]] const int tnt_u = SPLITW ? __builtin_amdgcn_readfirstlane((int)split_taint) : 0;
         if constexpr (unify) {
             i = __builtin_amdgcn_readfirstlane(i); r_end = __builtin_amdgcn_readfirstlane(r_end); qh = __builtin_amdgcn_readfirstlane(qh);
             prev_rs = __builtin_amdgcn_readfirstlane(prev_rs); prev_re = __builtin_amdgcn_readfirstlane(prev_re);
@@ -1035,8 +1038,14 @@ struct DevWave {
             "v_readlane_b32 %[t0], %[apos], %[qh]\n\t" \
             "s_cmp_gt_i32 %[t0], %[ilim]\n\t" \
             "s_cbranch_scc1 Lnc_end_%=\n\t"
-#define LZ_NC_ASM(WORD, WORDF) LZ_NC_ASM_X(WORD, WORDF, "")
-#define LZ_NC_ASM_X(WORD, WORDF, SPLCHK) \
+        /* (... and while its look-back is a lower bound of the true scan's -- split_taint -- only the record's own answers stand: they
+           hold for every look-back of aw symbols and more; what depends on the very reach is left to the machine) */
+#define LZ_NC_SPLITGEN \
+            "s_cmp_lg_u32 %[tnt], 0\n\t" \
+            "s_cbranch_scc1 Lnc_chk_%=\n\t"
+#define LZ_NC_SPLITIN , [tnt] "s"(tnt_u)
+#define LZ_NC_ASM(WORD, WORDF) LZ_NC_ASM_X(WORD, WORDF, "", "", )
+#define LZ_NC_ASM_X(WORD, WORDF, SPLCHK, SPLGEN, SPLIN) \
         asm volatile( \
             LZ_NC_PRIO_ON \
             "s_mov_b32 %[code], 0\n\t" \
@@ -1109,6 +1118,7 @@ struct DevWave {
             "s_mov_b32 %[fok], 1\n\t" \
             "s_branch Lnc_ok_%=\n" \
             "Lnc_gen_%=:\n\t" \
+            SPLGEN \
             "s_bitcmp0_b32 %[rec], 29\n\t"                  /* the forward extension must be in the record (empty or not) */ \
             "s_cbranch_scc1 Lnc_chk_%=\n\t" \
             "s_min_i32 %[t0], %[t1], %[ap]\n\t" \
@@ -1565,7 +1575,7 @@ struct DevWave {
               [gap] "=&s"(gap), [cls] "=&s"(cls), [fok] "=&s"(fok), [atm] "=&s"(add_tm), [atl] "=&s"(add_tl), [atc] "=&s"(add_tc), [m2] "=&s"(m2), \
               [rk0] "=&v"(rk0), [rk1] "=&v"(rk1), [qk] "=&v"(qk), [a0] "=&v"(a0), [a1] "=&v"(a1), [aq] "=&v"(aq), [t] "=&v"(t), [bq] "=&v"(bq), [w1] "=&v"(w1), [dumv] "=&v"(dumv), [qkb] "=&v"(qkb), [rk0b] "=&v"(rk0b), [rk1b] "=&v"(rk1b) \
             : [qc] "s"(qc_u), [ilim] "s"(ilim_u), [rlim] "s"(rlim_u), [qks] "s"(qks), [rks] "s"(rks), [ocl] "s"(ocl_u), [oclit] "s"(oclit_u), \
-              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS), \
+              [rt2] "s"(rt2), [qt2] "s"(qt2), [qend] "s"(qend), [wdum] "s"((int)SEED_BM_WORDS) SPLIN, \
               [apos] "v"(a_pos), [alen] "v"(a_len), [aref] "v"(a_ref), [aext] "v"(a_ext), [lane] "v"(lane), \
               [ldsb] "v"(ldsb), [zero] "v"(zero), [one] "v"(one), \
               [MQD] "n"(MQD), [MRD] "n"(MRD), [REG] "n"(REG), [AW] "n"(AW), [NT] "n"(NT), [WIN] "s"((int)WIN), [NR1] "n"(WIN - 64), [MSL] "n"(MSL), [MSL64] "n"(MSL + 64), [C41M] "n"(3 * MRD + 1 - WIN - MSL), [C40M] "n"(MRD - MSL), [CQ64] "n"(MRD + 64), [C2MRD] "n"(2 * MRD), \
@@ -1575,10 +1585,10 @@ struct DevWave {
         const unsigned long long pt_t0 = pt_now();
 #endif
         if constexpr (SPLITW) {
-            if constexpr (MSL == 9) { LZ_NC_ASM_X(LZ_NC_WORD9, LZ_NC_WORD9, LZ_NC_SPLITCHK) }
-            else if constexpr (MSL == 8) { LZ_NC_ASM_X(LZ_NC_WORD8, LZ_NC_WORD8, LZ_NC_SPLITCHK) }
-            else if constexpr (CP::NF) { LZ_NC_ASM_X(LZ_NC_WORD7, LZ_NC_WORD7N, LZ_NC_SPLITCHK) }
-            else { LZ_NC_ASM_X(LZ_NC_WORD7, LZ_NC_WORD7, LZ_NC_SPLITCHK) }
+            if constexpr (MSL == 9) { LZ_NC_ASM_X(LZ_NC_WORD9, LZ_NC_WORD9, LZ_NC_SPLITCHK, LZ_NC_SPLITGEN, LZ_NC_SPLITIN) }
+            else if constexpr (MSL == 8) { LZ_NC_ASM_X(LZ_NC_WORD8, LZ_NC_WORD8, LZ_NC_SPLITCHK, LZ_NC_SPLITGEN, LZ_NC_SPLITIN) }
+            else if constexpr (CP::NF) { LZ_NC_ASM_X(LZ_NC_WORD7, LZ_NC_WORD7N, LZ_NC_SPLITCHK, LZ_NC_SPLITGEN, LZ_NC_SPLITIN) }
+            else { LZ_NC_ASM_X(LZ_NC_WORD7, LZ_NC_WORD7, LZ_NC_SPLITCHK, LZ_NC_SPLITGEN, LZ_NC_SPLITIN) }
         } else
         if constexpr (MSL == 9) { LZ_NC_ASM(LZ_NC_WORD9, LZ_NC_WORD9) }
         else if constexpr (MSL == 8) { LZ_NC_ASM(LZ_NC_WORD8, LZ_NC_WORD8) }
@@ -2148,6 +2158,8 @@ struct DevWave {
 #undef LZ_NC_ASM
 #undef LZ_NC_ASM_X
 #undef LZ_NC_SPLITCHK
+#undef LZ_NC_SPLITGEN
+#undef LZ_NC_SPLITIN
 #undef LZ_NC_WORD7
 #undef LZ_NC_WORD7N
 #undef LZ_NC_WORD9

@@ -31,7 +31,7 @@ struct SplitArgs {
     const u32* work;             // this launch's items: p * S + segment (checkpoints: every (p, cut >= 1), no list)
     u32 n_work;
     u32* work_next;              // the stitch's: segments to run again
-    u32* counters;               // [0] tickets of the running launch, [1] items in work_next, [2] pairs finished
+    u32* counters;               // [0] tickets of the running launch, [1] items in work_next, [2] pairs finished, [4..11] void segments by cause
     unsigned char* done;         // per pair: stitched and stored
     int reg;
     int last_round;              // the stitch: a pair that still does not get through has all its cuts disabled and segment 0 listed
@@ -127,14 +127,15 @@ __global__ void __launch_bounds__(256) k_split_stitch(SplitArgs a)
     for (u32 p = blockIdx.x * blockDim.x + threadIdx.x; p < a.n_pairs; p += gridDim.x * blockDim.x) {
         if (a.done[p]) continue;
         SplitStart* const cuts = a.cuts + (u64)p * a.S;
-        int res[3], at = -1, from = -1;
-        if (split_stitch(cuts, a.outs + (u64)p * a.S, (int)a.S, a.reg, res, &at, &from)) {
+        int res[3], at = -1, from = -1, why = 5;
+        if (split_stitch(cuts, a.outs + (u64)p * a.S, (int)a.S, a.reg, res, &at, &from, &why)) {
             int* o = a.pa.out + 3 * (a.pa.cb_e0 + p);
             o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
             a.done[p] = 1;
             atomicAdd(&a.counters[2], 1u);
             continue;
         }
+        atomicAdd(&a.counters[4 + (why & 7)], 1u);          // (void segments by cause: the host's trace)
         u32 item;
         if (at < 0 || from < 0 || a.last_round) {          // nothing to retry (or out of rounds): segment 0 scans the pair whole
             for (u32 k = 1; k < a.S; ++k) cuts[k].i = -1;

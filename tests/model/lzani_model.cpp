@@ -97,6 +97,7 @@ struct HostWave {
     void emit_region(const RegionCoords& c) const { if (regs) regs->push_back(c); }
     void stamp(int) const {}
     void split_limit(int) const {}
+    void split_taint_set(bool) const {}
     int uniform(int v) const { return v; }
     bool ext_record(u32&) const { return false; }
     u64 mism_fwd(int q0, int r0, int n) const
