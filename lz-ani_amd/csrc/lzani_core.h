@@ -680,7 +680,7 @@ struct SplitOut {
     // bound -- good as long as every backward scan breaks inside it (else first = 2).
     int assumed;                     // at the close of the first region the segment went on as if the true scan 1 kept / 2 dropped it / 3 kept it, on a guess (0: not closed)
     int first_floor;                 // assumed = 2: the highest floor the segment's look-backs since hold for (the stitch wants the true floor at or below it);
-                                     // assumed = 3: the backward scan at the close was cut short
+                                     // assumed = 3: a backward scan at the close or since (up to the segment's next keep) was cut short
     int synced, floor;               // at the stop: the segment's floor is the true one (it kept a region) / its value
     int stop_i, stop_r;              // the state it stopped in (the checkpoint's i, r_end): with the fields above, all a RESUMED scan needs -- when the
                                      // segment it handed over to turns out void, that cut is disabled and this segment goes on from here
@@ -921,6 +921,7 @@ struct PairMachine {
         [[maybe_unused]] bool first_open = false;         // SPLIT 2: the region the segment started in is still open
         [[maybe_unused]] bool tainted = false;            //          how far back a distant match may look is known as a lower bound only
         [[maybe_unused]] int next_cut = 0, events = 0, lim_i = -1;
+        [[maybe_unused]] bool guess_line = false;         //          ... it kept its first region on a guess and has not kept another since
         [[maybe_unused]] bool floor_own = false;          //          ... it stands on its own floor (first region dropped by its own view): the true one may be HIGHER
         [[maybe_unused]] int need_floor = NO_CHECKPOINT;  //          ... and every look-back since holds for floors up to this one
         if constexpr (SPLIT == 1) { i = p0; cp->i = -1; cp->r_end = cp->prev_rs = cp->pre_lit = cp->cl = cp->clit = 0; }
@@ -932,6 +933,7 @@ struct PairMachine {
             g.tm = w.uniform(so->tm); g.tl = w.uniform(so->tl); g.tc = w.uniform(so->tc);
             first_open = w.uniform(so->first) == 0; tainted = w.uniform(so->synced) == 0;
             floor_own = tainted && w.uniform(so->assumed) == 2;
+            guess_line = tainted && w.uniform(so->assumed) == 3;
             if (floor_own) need_floor = w.uniform(so->first_floor);
             next_cut = w.uniform(so->stop) + 1;
             so->stop = -1;
@@ -1083,9 +1085,9 @@ struct PairMachine {
                         // only when the true scan drops.  So: kept, unless the region looks like a chance anchor's and the literals
                         // are too few for a backward scan to break in them)
                         if (!drop) { so->assumed = 1; tainted = false; }
-                        else if (lit >= 2 * P.aw || so->first_cl >= P.reg / 2) { so->assumed = 3; first_kept_guess = true; sure = false; }
+                        else if (lit >= 2 * P.aw || so->first_cl >= P.reg / 2) { so->assumed = 3; first_kept_guess = true; guess_line = true; sure = false; }
                         else { so->assumed = 2; so->first_floor = prev_rs - pre_lit; sure = false; floor_own = true; }
-                    } else if (tainted) { if (drop) sure = false; else { tainted = false; floor_own = false; } }
+                    } else if (tainted) { if (drop) sure = false; else { tainted = false; floor_own = false; guess_line = false; } }
                 }
                 if (__builtin_expect(drop && !first_kept_guess, 1)) {          // drop the short region
                     avail = pre_lit + (i - prev_rs);
@@ -1142,7 +1144,10 @@ struct PairMachine {
                     b = nb > 0 ? extend_backward(i, bpos, avail, true, Bb) : 0;
                 }
                 if constexpr (SPLIT == 2) {
-                    if (first_kept_guess) so->first_floor = bounded;          // (the stitch: void if the true scan dropped the region after all)
+                    // (kept on a guess, and every look-back up to the next keep: if the guess is right the segment's floor IS the true
+                    // one and a scan that runs to its bound is the true scan's; the stitch voids the segment only if the guess was wrong)
+                    if (first_kept_guess) so->first_floor = bounded;
+                    else if (!sure && bounded && guess_line) so->first_floor = 1;
                     else if (!sure && bounded) { so->first = 2; return; }     // the lower bound cut the scan short: void
                     if (floor_own) so->first_floor = need_floor;              // (the stitch: the true floor at or below it)
                 }

@@ -35,7 +35,7 @@ struct SplitArgs {
     unsigned char* done;         // per pair: stitched and stored
     int reg;
     int last_round;              // the stitch: a pair that still does not get through has all its cuts disabled and segment 0 listed
-    const unsigned char* heavy;  // per pair: cut it (a related pair: many anchor candidates); the others are scanned whole, by segment 0
+    const unsigned char* heavy;  // per pair: cut it (the others are scanned whole, by segment 0)
 };
 
 // the pair of batch-relative index p: its row (slot), reference, query and absolute result offset

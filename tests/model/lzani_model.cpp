@@ -7,6 +7,7 @@
 // fallback: nothing in lz-ani_amd/ links or loads it.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
