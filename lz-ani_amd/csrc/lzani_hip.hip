@@ -909,7 +909,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 }
                 c->tm.cand_launches += 2;
             }
-            if (lpt && c->d_lpt_cnt == nullptr) split_S = 0;     // (no counts after all: no split)
+            if (!lpt || c->d_lpt_cnt == nullptr) split_S = 0;    // (no candidate counts after all -- their buffer could not be had: no split)
             if (lpt && split_S < 2) {                        // the ticket order of the batch's queues
                 const u64 bp = e1 - e0;
                 QueueBounds qbv;
