@@ -899,7 +899,7 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 }
                 for (u32 q0 = 0; q0 < nq; q0 += 32768) {       // gridDim.y is limited to 65535
                     pg.q0 = q0;
-                    const dim3 gc(pm_tiles, std::min<u32>(32768, nq - q0)), bc(256);
+                    const dim3 gc(pm_tiles, std::min<u32>(32768, nq - q0)), bc(PM_CAND_THREADS);
                     switch (pg.rw / 4) {
                     case 1: hipLaunchKernelGGL(k_pm_cand<1>, gc, bc, lds, c->stream, pg); break;
                     case 2: hipLaunchKernelGGL(k_pm_cand<2>, gc, bc, lds, c->stream, pg); break;

@@ -140,8 +140,15 @@ __global__ void __launch_bounds__(256) k_pm_pairs(PmArgs a)
 // both fall on distinct banks.
 __device__ __forceinline__ u32 pm_tile_at(u32 rp1, u32 c, u32 s) { return c * rp1 + s; }
 
+// PM_CAND_THREADS threads a block: PM_TILE / PM_CAND_THREADS positions per thread (1,024: two blocks = 32 waves a CU beside 2 x 66 KB
+// of LDS tiles -- the matrix rows are random 64-byte reads, and the eight waves a CU of 256-thread blocks hid too little of
+// their latency: candidate stage of the 10k bench 23.8 -> 18.7 ms with 512 threads, ~17 ms with 1,024: round 4)
+#ifndef LZANI_PM_CAND_THREADS
+#define LZANI_PM_CAND_THREADS 1024
+#endif
+enum { PM_CAND_THREADS = LZANI_PM_CAND_THREADS, PM_CAND_PER = PM_TILE / PM_CAND_THREADS };
 template <int RW4>         // RW4 = rw / 4: 16-byte loads per matrix row
-__global__ void __launch_bounds__(256) k_pm_cand(PmArgs a)
+__global__ void __launch_bounds__(PM_CAND_THREADS) k_pm_cand(PmArgs a)
 {
     extern __shared__ u32 s_tile[];                    // 32 x (RP + 1) words, then RP pair indexes
     const u32 RP = 128u * RW4, rp1 = RP + 1;
@@ -154,8 +161,8 @@ __global__ void __launch_bounds__(256) k_pm_cand(PmArgs a)
     const int D = a.G.L[q] + a.mrd;
     const int p0 = (int)blockIdx.x * PM_TILE;
     if (p0 >= D + 320) return;                         // (block-uniform) the pair kernel reads five words beyond its scan position at most
-    for (u32 k = threadIdx.x; k < PM_TILE_WORDS * rp1; k += 256) s_tile[k] = 0;
-    for (u32 s = threadIdx.x; s < RP; s += 256) {
+    for (u32 k = threadIdx.x; k < PM_TILE_WORDS * rp1; k += PM_CAND_THREADS) s_tile[k] = 0;
+    for (u32 s = threadIdx.x; s < RP; s += PM_CAND_THREADS) {
         u32 pe = 0xFFFFFFFFu;
         if (a.pidx) pe = a.pidx[(u64)q * RP + s];
         else if (s < a.rows) {
@@ -165,24 +172,24 @@ __global__ void __launch_bounds__(256) k_pm_cand(PmArgs a)
         s_pair[s] = pe;
     }
     const u32* km = a.G.kmL + 64 * a.G.nmoff[q];
-    // four positions per thread; their k-mer words, then their matrix rows, requested together
-    u32 h[4];
-    uint4 row[4][RW4];
+    // PM_CAND_PER positions per thread; their k-mer words, then their matrix rows, requested together
+    u32 h[PM_CAND_PER];
+    uint4 row[PM_CAND_PER][RW4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int p = p0 + k * 256 + (int)threadIdx.x;
+    for (int k = 0; k < PM_CAND_PER; ++k) {
+        const int p = p0 + k * PM_CAND_THREADS + (int)threadIdx.x;
         h[k] = p < D ? km[p] : KM_INVALID;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PM_CAND_PER; ++k) {
         const uint4* src = reinterpret_cast<const uint4*>(a.M + (u64)(h[k] == KM_INVALID ? 0u : ((h[k] >> a.rshift) & a.mmask)) * a.rw);
 #pragma unroll
         for (int j = 0; j < RW4; ++j) row[k][j] = src[j];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const u32 pl = (u32)k * 256u + threadIdx.x;    // position inside the tile
+    for (int k = 0; k < PM_CAND_PER; ++k) {
+        const u32 pl = (u32)k * (u32)PM_CAND_THREADS + threadIdx.x;    // position inside the tile
         const u32 c = pl >> 5, bit = 1u << (pl & 31);
         const bool ok = h[k] != KM_INVALID;
 #pragma unroll
@@ -202,7 +209,7 @@ __global__ void __launch_bounds__(256) k_pm_cand(PmArgs a)
     __syncthreads();
     // write-out: 32 lanes = the 128-byte line of one pair
     const u32 c = threadIdx.x & 31;
-    for (u32 s = threadIdx.x >> 5; s < a.rows; s += 8) {
+    for (u32 s = threadIdx.x >> 5; s < a.rows; s += PM_CAND_THREADS / 32) {
         const u32 pe = s_pair[s];
         const u32 wv = s_tile[pm_tile_at(rp1, c, s)];
         if (pe != 0xFFFFFFFFu) a.cbits[(u64)pe * a.cb_words + (u64)blockIdx.x * PM_TILE_WORDS + c] = wv;
