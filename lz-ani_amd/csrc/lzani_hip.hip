@@ -850,7 +850,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 // the matrix: from the group's indexes, chunk by chunk through LDS (long genomes: no global atomics, no clearing),
                 // or by one atomicOr per text position into the cleared matrix
                 const int tbits = c->geo.kb - c->geo.dirbits;
-                const int rcl = std::min(pm_bits, pg.rw <= 4 ? 13 : pg.rw <= 8 ? 12 : 11);
+                // (chunks of 64 KB: two blocks = 32 waves a CU; with 128 KB chunks, one block a CU, the matrix of 128 x 5 Mbp took 3 ms more)
+                const int rcl = std::min(pm_bits, pg.rw <= 4 ? 12 : pg.rw <= 8 ? 11 : 10);
                 const char* fie = getenv("LZANI_PM_FROM_INDEX");
                 const bool from_index = c->geo.tagmask == (u32)lowmask(tbits) && pm_bits == c->geo.kb && rcl >= tbits &&
                                         (fie ? *fie == '1' : pm_bits > 24);

@@ -338,7 +338,11 @@ __global__ void k_idx_fill(IdxArgs a, int Tmax)
 // so that every global access is coalesced and all random traffic stays in LDS.  A reference that does not
 // fit (a range with more than IDX_STAGE entries or a bucket of 65,535: long low-complexity runs) sets
 // status[slot] and is rebuilt by the global-atomics kernels, which skip every other slot.
-enum { IDX_RANGE = 16384, IDX_STAGE = 24576 };       // 32 KB of counters + 96 KB of staging
+#ifndef LZANI_IDX_RANGE
+#define LZANI_IDX_RANGE 16384
+#define LZANI_IDX_STAGE 24576
+#endif
+enum { IDX_RANGE = LZANI_IDX_RANGE, IDX_STAGE = LZANI_IDX_STAGE };       // 32 KB of counters + 96 KB of staging
 
 __global__ void __launch_bounds__(1024) k_idx_build(IdxArgs a, u32* __restrict__ bk, u32* __restrict__ tw,
                                                     u64 bk_stride, u64 tw_stride, u32* __restrict__ status)

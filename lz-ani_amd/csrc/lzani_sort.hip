@@ -24,7 +24,10 @@ namespace {
 typedef unsigned long long u64;
 typedef uint32_t u32;
 
-enum { RS_BITS = 8, RS_BINS = 1 << RS_BITS, RS_THREADS = 512, RS_WAVES = RS_THREADS / 64, RS_PER_THREAD = 16,
+#ifndef LZANI_RS_PER_THREAD
+#define LZANI_RS_PER_THREAD 16
+#endif
+enum { RS_BITS = 8, RS_BINS = 1 << RS_BITS, RS_THREADS = 512, RS_WAVES = RS_THREADS / 64, RS_PER_THREAD = LZANI_RS_PER_THREAD,
        RS_TILE = RS_THREADS * RS_PER_THREAD, RS_WAVE_KEYS = 64 * RS_PER_THREAD };
 
 __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const u64* __restrict__ keys, u64 seg_len, u32 tiles, int shift, u32 dmask,
