@@ -45,7 +45,7 @@ with open(os.path.join(d, "out.tsv")) as f:
         qn, rn, mat, lit, aln = ln.rstrip("\n").split("\t")
         qi, ri = int(qn[1:7]), int(rn[1:7])
         related = qi // 10 == ri // 10
-        if (related and want_rel > 0 and (k * 2654435761) % 2**32 < 2**32 // 40) or (not related and (k * 2654435761) % 2**32 < 2**32 // 3000):
+        if n * (n - 1) <= check or (related and want_rel > 0 and (k * 2654435761) % 2**32 < 2**32 // 40) or (not related and (k * 2654435761) % 2**32 < 2**32 // 3000):
             picks.append((ri, qi, int(mat), int(lit), int(aln)))
             want_rel -= related
 # the sampled pairs through the reference's parser, all host threads at once (serially through the C restatement where
