@@ -1053,7 +1053,7 @@ def test_filtered_rows_of_mid_size_genomes_with_long_kmers(monkeypatch):
     print(f"768 x 100 kbp at mal 15, filtered rows of 32 queries ({len(qq)} pairs): {t_pm * 1e3:.1f} ms with candidate bitmaps "
           f"(index {tm['index_ms']:.1f}, candidate stage {tm['cand_ms']:.1f}, pair kernel {tm['pairs_ms']:.1f}), "
           f"{t_rounds * 1e3:.1f} ms by rounds (index {tm0['index_ms']:.1f}, pair kernel {tm0['pairs_ms']:.1f})")
-    assert t_pm * 1.4 < t_rounds, (t_pm, t_rounds)
+    assert t_pm * 1.2 < t_rounds, (t_pm, t_rounds)          # (1.9x when measured; a timing assertion gets room)
 
 
 def test_block_kernel_with_lds_filter(monkeypatch):
