@@ -802,7 +802,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             // with 992 pairs the rounds of segments run again cost more than the cuts save: from 16 wave slots per pair on)
             const bool on = se ? *se == '1' : (cb_words >= 8192 && bp * 16 <= slots);
             if (on && bp * 2 <= 0xFFFFFFFFull / 64) {
-                u32 S = (u32)std::min<u64>(16, std::max<u64>(2, slots / bp));
+                const char* sse = getenv("LZANI_SPLIT_S");
+                u32 S = (u32)std::min<u64>(sse ? (u64)std::max(2, atoi(sse)) : 64, std::max<u64>(2, slots / bp));      // (8 x 5 Mbp: 67 / 58 / 42 ms a launch with 16 / 32 / 64 a pair)
                 int seglen = (Dmax + (int)S - 1) / (int)S;
                 if (sl && atoi(sl) > 0) { seglen = atoi(sl); S = (u32)std::min<int>(64, std::max(2, (Dmax + seglen - 1) / seglen)); }
                 seglen = std::max(seglen, 512);
@@ -1051,11 +1052,12 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
                 launch(0, npb * (S - 1));                                  // the checkpoints
                 u32* cur = d_work.p; u32* nxt = d_next.p;
                 auto t_round = std::chrono::steady_clock::now();
-                for (int round = 0; round < 12 && items; ++round) {
+                const int give_up = 6 + (int)S / 4;                      // (a chain of void segments costs a round each: more segments, more rounds allowed)
+                for (int round = 0; round < give_up + 4 && items; ++round) {
                     HIPCHK(c, hipMemsetAsync(d_cnt.p, 0, 8, c->stream));     // tickets, next round's items (the finished pairs' count stays)
                     sa.work = cur; sa.work_next = nxt;
                     launch(1, items);
-                    sa.last_round = round >= 6;
+                    sa.last_round = round >= give_up;
                     hipLaunchKernelGGL(k_split_stitch, dim3((npb + 255) / 256), dim3(256), 0, c->stream, sa);
                     u32 cnt[12] = {0};
                     HIPCHK(c, hipMemcpyAsync(cnt, d_cnt.p, 48, hipMemcpyDeviceToHost, c->stream));
