@@ -2,5 +2,5 @@
 # GPU box: path counters and section shares of the related workload (diagnostic builds)
 set -o pipefail
 mkdir -p gpurun_out
-bash tools/r4_paths.sh || exit 1
-bash tools/r4_stamps.sh
+bash tools/runs/r4_paths.sh || exit 1
+bash tools/runs/r4_stamps.sh
