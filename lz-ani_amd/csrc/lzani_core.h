@@ -663,6 +663,9 @@ template <class W> struct wave_has_stretch_chain<W, std::void_t<decltype(W::HAS_
 #ifdef LZ_SPLIT_DEBUG
 static long g_split_why[8];
 #endif
+#ifndef LZ_SPLIT_GUESS_LIT
+#define LZ_SPLIT_GUESS_LIT 4          // a short first region is kept on a guess from this many half-windows of literals on (see run_impl)
+#endif
 struct SplitStart {                  // where a segment starts: the state behind the first event of a fresh scan from the cut
     int i, r_end, prev_rs, pre_lit, cl, clit;        // lit = 0, tracking, prev_re = i, nl = 0;  i = -1: no checkpoint (no event behind the cut, or the cut is disabled)
 };
@@ -956,11 +959,14 @@ struct PairMachine {
             if (++rounds > D + 8) { LZ_GUARD_TRIP(3); out[0] = -1; out[1] = i; out[2] = lit; return; }
             if constexpr (SPLIT == 1) {
                 if (events && trk && lit == 0) {
-                    // behind an event of the fresh scan's FIRST region: a checkpoint (an event leaves lit = 0, tracking).  The later the
-                    // better, up to a point: once the region spans reg positions the segment that starts here knows how it will be
-                    // closed (kept) -- a shorter piece of a long true region is what voids most segments of related pairs
+                    // behind an event of the fresh scan: a checkpoint (an event leaves lit = 0, tracking; where the scan STANDS does not
+                    // depend on the region bookkeeping at all, so every such state is on the true scan's way once the two have
+                    // met).  The later the better, up to a point: once the open region spans reg positions the segment that starts
+                    // here knows how it will be closed (kept) -- a first region that is short in the segment's view is what voids
+                    // most segments (kept or dropped by the true scan? a guess either way).  The search gives up after 64 events or
+                    // 16 k positions (a zone where nothing is kept) and takes the last state.
                     cp->i = i; cp->r_end = r_end; cp->prev_rs = prev_rs; cp->pre_lit = pre_lit; cp->cl = g.cl; cp->clit = g.clit;
-                    if (prev_re - prev_rs >= P.reg || events >= 8) return;
+                    if (prev_re - prev_rs >= P.reg || events >= 64 || i - p0 > 16384) return;
                 }
             }
             if constexpr (SPLIT == 2) {
@@ -1044,8 +1050,6 @@ struct PairMachine {
                 continue;
             }
             if constexpr (SPLIT == 1) {
-                // (a distant match behind the first event would close the first region: the checkpoint is the state before it)
-                if (events && !(trk && lit <= P.mqd && iabs(bpos - (r_end + lit)) <= P.mrd)) return;
                 events += 1;
             }
 #if defined(LZANI_EXP) && LZANI_EXP >= 1                     // diagnostic build: events found but not processed
@@ -1085,7 +1089,7 @@ struct PairMachine {
                         // only when the true scan drops.  So: kept, unless the region looks like a chance anchor's and the literals
                         // are too few for a backward scan to break in them)
                         if (!drop) { so->assumed = 1; tainted = false; }
-                        else if (lit >= 2 * P.aw || so->first_cl >= P.reg / 2) { so->assumed = 3; first_kept_guess = true; guess_line = true; sure = false; }
+                        else if (lit >= LZ_SPLIT_GUESS_LIT * P.aw / 2 || so->first_cl >= P.reg / 2) { so->assumed = 3; first_kept_guess = true; guess_line = true; sure = false; }
                         else { so->assumed = 2; so->first_floor = prev_rs - pre_lit; sure = false; floor_own = true; }
                     } else if (tainted) { if (drop) sure = false; else { tainted = false; floor_own = false; guess_line = false; } }
                 }
