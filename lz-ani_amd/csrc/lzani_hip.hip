@@ -800,7 +800,8 @@ int run_rows_impl(lzani_ctx* c, u32 n_rows, const u32* ref_ids, const u64* row_o
             const int Dmax = Lmax + c->P.mrd;
             // (measured at the end of round 4, 5 Mbp: 56 pairs 6 ms a launch instead of 148, 240 pairs 8 instead of 147, 992 pairs 47
             // instead of 148: from 8 wave slots per pair on)
-            const bool on = se ? *se == '1' : (cb_words >= 8192 && bp * 8 <= slots);
+            // (... measured at 5 Mbp; for shorter queries -- from 256 kbp on -- from 16 wave slots per pair, as the suite has run it)
+            const bool on = se ? *se == '1' : (cb_words >= 8192 && (bp * 16 <= slots || (cb_words >= 65536 && bp * 8 <= slots)));
             if (on && bp * 2 <= 0xFFFFFFFFull / 64) {
                 const char* sse = getenv("LZANI_SPLIT_S");
                 u32 S = (u32)std::min<u64>(sse ? (u64)std::max(2, atoi(sse)) : 64, std::max<u64>(2, slots / bp));      // (8 x 5 Mbp: 67 / 58 / 42 ms a launch with 16 / 32 / 64 a pair)
